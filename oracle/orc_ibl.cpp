@@ -1,0 +1,158 @@
+// TEST INFRASTRUCTURE — CPU restatement ("oracle"); see orc_types.h.
+//
+// Cube-map sampling and the two image-based-lighting bakes
+// (Renderer/VulkanRendererEnvironment.cpp:193-250 irradiance, :324-391
+// GGX prefilter; shaders envbake.vert, envbakediffuse.frag,
+// envbakespecular.frag). Cube face selection and face coordinates follow the
+// Vulkan 1.3 "Cube Map Face Selection" tables; filtering is bilinear inside
+// the selected face with clamp-to-edge (no cross-face taps), the same choice
+// as the HIP path.
+#include <algorithm>
+#include <cmath>
+
+#include "orc_types.h"
+
+namespace orc {
+
+// Vulkan cube face selection: major axis = largest magnitude, z wins ties over
+// y over x. Returns face (0..5 = +X,-X,+Y,-Y,+Z,-Z) and (s,t) in [0,1].
+static inline int cube_face(float rx, float ry, float rz, float& s, float& t) {
+    const float ax = std::fabs(rx), ay = std::fabs(ry), az = std::fabs(rz);
+    int face; float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = rz < 0.0f ? 5 : 4; sc = rz < 0.0f ? -rx : rx; tc = -ry; ma = az; }
+    else if (ay >= ax) { face = ry < 0.0f ? 3 : 2; sc = rx; tc = ry < 0.0f ? -rz : rz; ma = ay; }
+    else { face = rx < 0.0f ? 1 : 0; sc = rx < 0.0f ? rz : -rz; tc = -ry; ma = ax; }
+    s = 0.5f * (sc / ma) + 0.5f;
+    t = 0.5f * (tc / ma) + 0.5f;
+    return face;
+}
+
+void cube_sample(const Cube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
+    float s, t;
+    const int face = cube_face(dx, dy, dz, s, t);
+    const int r = (int)std::max(1u, cube.res >> level);
+    const uint32_t* px = cube.level[level].data() + (size_t)face * r * r;
+    const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
+    const float fu = std::floor(tu), fv = std::floor(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = std::min(std::max((int)fu, 0), r - 1), i1 = std::min(std::max((int)fu + 1, 0), r - 1);
+    const int j0 = std::min(std::max((int)fv, 0), r - 1), j1 = std::min(std::max((int)fv + 1, 0), r - 1);
+    float c00[3], c10[3], c01[3], c11[3];
+    unpack_r11g11b10(px[(size_t)j0 * r + i0], c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(px[(size_t)j0 * r + i1], c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(px[(size_t)j1 * r + i0], c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(px[(size_t)j1 * r + i1], c11[0], c11[1], c11[2]);
+    for (int k = 0; k < 3; k++) {
+        const float top = (1.0f - a) * c00[k] + a * c10[k], bot = (1.0f - a) * c01[k] + a * c11[k];
+        out[k] = (1.0f - b) * top + b * bot;
+    }
+}
+
+// Direction through the centre of texel (x,y) of `face` for a res x res bake.
+// envbake.vert:21-24 pushes inverse(proj*view) with proj = scale(1,-1,1) and
+// the per-face view rotations of VulkanRendererEnvironment.cpp:209-217; the
+// fullscreen quad sits at z = 1, so position = inverse(view) * (xn, -yn, 1).
+// With the rotation matrices written out (R^-1 = R^T) that is:
+static inline V3 bake_direction(int face, int x, int y, int res) {
+    const float xn = ((float)x + 0.5f) * (2.0f / (float)res) - 1.0f;
+    const float yn = ((float)y + 0.5f) * (2.0f / (float)res) - 1.0f;
+    const float vx = xn, vy = -yn, vz = 1.0f;  // view-space position after undoing proj
+    switch (face) {
+        case 0: return {vz, vy, -vx};    // view = Ry(-90deg)
+        case 1: return {-vz, vy, vx};    // view = Ry(+90deg)
+        case 2: return {vx, vz, -vy};    // view = Rx(+90deg)
+        case 3: return {vx, -vz, vy};    // view = Rx(-90deg)
+        case 4: return {vx, vy, vz};     // identity
+        default: return {-vx, vy, -vz};  // view = Ry(180deg)
+    }
+}
+
+// envbakediffuse.frag:12-40, 256^2 per face (VulkanRenderer.h:220)
+void bake_irradiance(Ctx& c) {
+    const int res = 256;
+    c.irradiance.res = res; c.irradiance.levels = 1;
+    c.irradiance.level.assign(1, std::vector<uint32_t>((size_t)6 * res * res));
+    const float PI = 3.14159265359f;
+    const int nSamples = 24;
+    const float stepRads = 2 * PI / nSamples;
+#pragma omp parallel for schedule(dynamic, 16) collapse(2)
+    for (int face = 0; face < 6; face++)
+        for (int y = 0; y < res; y++)
+            for (int x = 0; x < res; x++) {
+                V3 normal = normalize(bake_direction(face, x, y, res));
+                V3 up{0.0f, 1.0f, 0.0f};
+                V3 right = normalize(cross(up, normal));
+                up = normalize(cross(normal, right));
+                float irr[3] = {0, 0, 0};
+                for (int i = 0; i < nSamples; i++)
+                    for (int j = 0; j < nSamples / 4; j++) {
+                        const float phi = i * stepRads, theta = j * stepRads;
+                        const float st = std::sin(theta), ct = std::cos(theta);
+                        const float tx = st * std::cos(phi), ty = st * std::sin(phi), tz = ct;
+                        V3 sv = right * tx + up * ty + normal * tz;
+                        float e[3];
+                        cube_sample(c.env, 0, sv.x, sv.y, sv.z, e);
+                        for (int k = 0; k < 3; k++) irr[k] += e[k] * ct * st;
+                    }
+                const float norm = 1.0f / (float)(nSamples * nSamples / 4);
+                for (int k = 0; k < 3; k++) irr[k] = PI * irr[k] * norm;
+                c.irradiance.level[0][((size_t)face * res + y) * res + x] = pack_r11g11b10(irr[0], irr[1], irr[2]);
+            }
+}
+
+// envbakespecular.frag:17-30
+static inline float radical_inverse(uint32_t bits) {
+    bits = (bits << 16u) | (bits >> 16u);
+    bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
+    bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
+    bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
+    bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+    return (float)bits * 2.3283064365386963e-10f;
+}
+
+// envbakespecular.frag:32-86; 512^2 base, 10 levels, roughness = level/9
+// (VulkanRenderer.h:225, VulkanRendererEnvironment.cpp:350-360)
+void bake_prefiltered(Ctx& c) {
+    const int base = 512, levels = 10;
+    c.prefiltered.res = base; c.prefiltered.levels = levels;
+    c.prefiltered.level.resize(levels);
+    const float PI = 3.14159265359f;
+    const int nSamples = 128;
+    for (int l = 0; l < levels; l++) {
+        const int res = base >> l;
+        const float roughness = (float)l / 9;
+        c.prefiltered.level[l].assign((size_t)6 * res * res, 0u);
+#pragma omp parallel for schedule(dynamic, 16) collapse(2)
+        for (int face = 0; face < 6; face++)
+            for (int y = 0; y < res; y++)
+                for (int x = 0; x < res; x++) {
+                    const V3 N = normalize(bake_direction(face, x, y, res));
+                    const V3 V = N;
+                    float col[3] = {0, 0, 0}, total = 0.0f;
+                    for (int i = 0; i < nSamples; i++) {
+                        const float xi_x = (float)i / (float)nSamples, xi_y = radical_inverse((uint32_t)i);
+                        const float a = roughness * roughness;
+                        const float phi = 2.0f * PI * xi_x;
+                        const float cosTheta = std::sqrt((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
+                        const float sinTheta = std::sqrt(1.0f - cosTheta * cosTheta);
+                        const V3 Ht{std::cos(phi) * sinTheta, std::sin(phi) * sinTheta, cosTheta};
+                        const V3 upv = std::fabs(N.z) < 0.999f ? V3{0, 0, 1} : V3{1, 0, 0};
+                        const V3 tangent = normalize(cross(upv, N));
+                        const V3 bitangent = cross(N, tangent);
+                        const V3 H = normalize(tangent * Ht.x + bitangent * Ht.y + N * Ht.z);
+                        const V3 L = normalize(H * (2.0f * dot(V, H)) - V);
+                        const float NdotL = std::max(dot(N, L), 0.0f);
+                        if (NdotL > 0.0f) {
+                            float e[3];
+                            cube_sample(c.env, 0, L.x, L.y, L.z, e);
+                            for (int k = 0; k < 3; k++) col[k] += e[k] * NdotL;
+                            total += NdotL;
+                        }
+                    }
+                    for (int k = 0; k < 3; k++) col[k] /= total;
+                    c.prefiltered.level[l][((size_t)face * res + y) * res + x] = pack_r11g11b10(col[0], col[1], col[2]);
+                }
+    }
+}
+
+}  // namespace orc

@@ -1,0 +1,237 @@
+// TEST INFRASTRUCTURE — CPU restatement ("oracle"); see orc_types.h.
+//
+// Vertex stage + fixed-function rasterisation of the reference's depth-tested
+// triangle-list draws. The reference hands this work to the Vulkan driver
+// (pipeline state: Renderer/VulkanRenderer.cpp:836-866 main pass,
+// Renderer/VulkanRendererShadow.cpp:72-118 shadow pass); the rules below are
+// the Vulkan 1.3 ones (clip volume 0<=z<=w, top-left fill rule, standard
+// sample locations, depth LESS) with these implementation choices, shared
+// with the HIP path so that depth and coverage can be compared bit for bit:
+//   * clip position = fma chain  m0*x + (m1*y + (m2*z + m3))  in float
+//   * polygon clipping (Sutherland-Hodgman) against near, far and a guard band
+//     of +-16384 px around the viewport centre; a plane is only applied when
+//     an input vertex lies outside it; intersections are computed from the
+//     inside vertex towards the outside one
+//   * window coordinates snapped to 1/256 px (round to nearest even)
+//   * edge functions in exact integer arithmetic
+//   * depth = plane through the three UNCLIPPED vertices, solved in double
+//     from their homogeneous (x,y,w), evaluated in double at the sample,
+//     rounded to float and clamped to [0,1]
+#include <algorithm>
+#include <cmath>
+
+#include "orc_types.h"
+
+namespace orc {
+
+struct ClipV { float x, y, z, w; };
+
+static inline ClipV xform(const M4& m, V3 p) {
+    ClipV r;
+    r.x = std::fmaf(m.c[0][0], p.x, std::fmaf(m.c[1][0], p.y, std::fmaf(m.c[2][0], p.z, m.c[3][0])));
+    r.y = std::fmaf(m.c[0][1], p.x, std::fmaf(m.c[1][1], p.y, std::fmaf(m.c[2][1], p.z, m.c[3][1])));
+    r.z = std::fmaf(m.c[0][2], p.x, std::fmaf(m.c[1][2], p.y, std::fmaf(m.c[2][2], p.z, m.c[3][2])));
+    r.w = std::fmaf(m.c[0][3], p.x, std::fmaf(m.c[1][3], p.y, std::fmaf(m.c[2][3], p.z, m.c[3][3])));
+    return r;
+}
+
+static inline float plane_dist(const ClipV& v, int plane, float kx, float ky) {
+    switch (plane) {
+        case 0: return v.z;                       // near: z >= 0
+        case 1: return v.w - v.z;                 // far:  z <= w
+        case 2: return std::fmaf(kx, v.w, v.x);   // x >= -kx w
+        case 3: return std::fmaf(kx, v.w, -v.x);  // x <=  kx w
+        case 4: return std::fmaf(ky, v.w, v.y);
+        default: return std::fmaf(ky, v.w, -v.y);
+    }
+}
+
+// MSAA standard sample locations (Vulkan spec, "Multisampling"), in 1/256 px
+static const int kSampleX4[4] = {96, 224, 32, 160};
+static const int kSampleY4[4] = {32, 96, 160, 224};
+
+struct SetupRec {
+    int32_t X[9], Y[9];
+    int32_t n;  // 0 = dropped
+    int32_t ix0, ix1, iy0, iy1;
+    uint32_t id;
+    double dzdX, dzdY, z00;
+};
+
+// Everything per triangle that does not depend on the sample: clip, snap,
+// facing, bounding box, depth plane. Returns false when the triangle is dropped.
+static bool setup_triangle(const Draw& d, const Primitive& pr, size_t t, int W, int H, int S, CullMode cull, SetupRec& r) {
+    const float kx = 32768.0f / (float)W, ky = 32768.0f / (float)H;
+    const float halfW256 = 128.0f * (float)W, halfH256 = 128.0f * (float)H;
+    const double sx = 2.0 / (256.0 * (double)W), sy = 2.0 / (256.0 * (double)H);
+    r.n = 0;
+    const V3 p0 = pr.pos[pr.idx[3 * t]], p1 = pr.pos[pr.idx[3 * t + 1]], p2 = pr.pos[pr.idx[3 * t + 2]];
+    ClipV cv[3] = {xform(d.mvp, p0), xform(d.mvp, p1), xform(d.mvp, p2)};
+    for (int i = 0; i < 3; i++)
+        if (!(std::isfinite(cv[i].x) && std::isfinite(cv[i].y) && std::isfinite(cv[i].z) && std::isfinite(cv[i].w))) return false;
+
+    // ---- clip
+    ClipV poly[12], tmp[12];
+    int n = 3;
+    poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2];
+    for (int plane = 0; plane < 6; plane++) {
+        int outside = 0;
+        for (int i = 0; i < 3; i++) outside += plane_dist(cv[i], plane, kx, ky) < 0.0f;
+        if (outside == 0) continue;
+        if (outside == 3) return false;
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const ClipV& a = poly[i];
+            const ClipV& b = poly[(i + 1) % n];
+            const float da = plane_dist(a, plane, kx, ky), db = plane_dist(b, plane, kx, ky);
+            const bool ina = da >= 0.0f, inb = db >= 0.0f;
+            if (ina) tmp[m++] = a;
+            if (ina != inb) {
+                const ClipV& in = ina ? a : b;
+                const ClipV& out = ina ? b : a;
+                const float din = ina ? da : db, dout = ina ? db : da;
+                const float tt = din / (din - dout);
+                ClipV q;
+                q.x = std::fmaf(tt, out.x - in.x, in.x);
+                q.y = std::fmaf(tt, out.y - in.y, in.y);
+                q.z = std::fmaf(tt, out.z - in.z, in.z);
+                q.w = std::fmaf(tt, out.w - in.w, in.w);
+                tmp[m++] = q;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; i++) poly[i] = tmp[i];
+        if (n < 3) return false;
+    }
+    if (n > 9) return false;  // cannot happen: a triangle cut by 6 planes has at most 9 vertices
+
+    // ---- project + snap to 1/256 px
+    int32_t* X = r.X; int32_t* Y = r.Y;
+    for (int i = 0; i < n; i++) {
+        const float xn = poly[i].x / poly[i].w, yn = poly[i].y / poly[i].w;
+        const float fx = std::rint(std::fmaf(xn, halfW256, halfW256));
+        const float fy = std::rint(std::fmaf(yn, halfH256, halfH256));
+        if (!(std::fabs(fx) <= 16777216.0f) || !(std::fabs(fy) <= 16777216.0f)) return false;
+        X[i] = (int32_t)fx; Y[i] = (int32_t)fy;
+    }
+
+    // ---- facing (Vulkan: a = -1/2 sum(x_i y_i+1 - x_i+1 y_i); CCW front => front iff sum < 0)
+    int64_t area2 = 0;
+    for (int i = 0; i < n; i++) {
+        const int j = (i + 1) % n;
+        area2 += (int64_t)X[i] * Y[j] - (int64_t)X[j] * Y[i];
+    }
+    if (area2 == 0) return false;
+    const bool front = area2 < 0;
+    if ((cull == CULL_BACK && !front) || (cull == CULL_FRONT && front)) return false;
+    if (area2 < 0) {  // orient so that the interior has positive edge functions
+        std::reverse(X, X + n);
+        std::reverse(Y, Y + n);
+    }
+
+    // ---- pixel bounding box
+    int32_t minX = X[0], maxX = X[0], minY = Y[0], maxY = Y[0];
+    for (int i = 1; i < n; i++) {
+        minX = std::min(minX, X[i]); maxX = std::max(maxX, X[i]);
+        minY = std::min(minY, Y[i]); maxY = std::max(maxY, Y[i]);
+    }
+    int ix0, ix1, iy0, iy1;
+    if (S == 1) {  // pixels whose centre lies in the box
+        ix0 = (minX - 128 + 255) >> 8; ix1 = (maxX - 128) >> 8;
+        iy0 = (minY - 128 + 255) >> 8; iy1 = (maxY - 128) >> 8;
+    } else {       // pixels that the box touches
+        ix0 = minX >> 8; ix1 = maxX >> 8; iy0 = minY >> 8; iy1 = maxY >> 8;
+    }
+    ix0 = std::max(ix0, 0); iy0 = std::max(iy0, 0);
+    ix1 = std::min(ix1, W - 1); iy1 = std::min(iy1, H - 1);
+    if (ix0 > ix1 || iy0 > iy1) return false;
+    r.ix0 = ix0; r.ix1 = ix1; r.iy0 = iy0; r.iy1 = iy1;
+
+    // ---- depth plane from the unclipped homogeneous vertices: a x + b y + c w = z
+    const double x0 = cv[0].x, y0 = cv[0].y, z0 = cv[0].z, w0 = cv[0].w;
+    const double x1 = cv[1].x, y1 = cv[1].y, z1 = cv[1].z, w1 = cv[1].w;
+    const double x2 = cv[2].x, y2 = cv[2].y, z2 = cv[2].z, w2 = cv[2].w;
+    const double m_yw = y1 * w2 - y2 * w1, m_xw = x1 * w2 - x2 * w1, m_xy = x1 * y2 - x2 * y1;
+    const double m_zw = z1 * w2 - z2 * w1, m_zy = z1 * y2 - z2 * y1, m_xz = x1 * z2 - x2 * z1;
+    const double m_yz = y1 * z2 - y2 * z1;
+    const double det = (x0 * m_yw - y0 * m_xw) + w0 * m_xy;
+    if (det == 0.0 || !std::isfinite(det)) return false;
+    const double pa = ((z0 * m_yw - y0 * m_zw) + w0 * m_zy) / det;
+    const double pb = ((x0 * m_zw - z0 * m_xw) + w0 * m_xz) / det;
+    const double pc = ((x0 * m_yz - y0 * m_xz) + z0 * m_xy) / det;
+    r.dzdX = pa * sx; r.dzdY = pb * sy; r.z00 = (pc - pa) - pb;
+    if (!std::isfinite(r.dzdX) || !std::isfinite(r.dzdY) || !std::isfinite(r.z00)) return false;
+    r.id = d.first_tri + (uint32_t)t;
+    r.n = n;
+    return true;
+}
+
+void raster_draws(const Ctx& c, const std::vector<Draw>& draws, const RasterTarget& rt, CullMode cull,
+                  uint64_t* tri_instances, uint64_t* tri_binned) {
+    const int W = (int)rt.w, H = (int)rt.h;
+    const int S = (int)rt.samples;
+
+    // phase 1: per-triangle setup, kept in submission order
+    std::vector<size_t> first(draws.size() + 1, 0);
+    for (size_t i = 0; i < draws.size(); i++) first[i + 1] = first[i] + c.prims[draws[i].prim].idx.size() / 3;
+    const size_t total = first.back();
+    std::vector<SetupRec> recs(total);
+    uint64_t n_binned = 0;
+    for (size_t di = 0; di < draws.size(); di++) {
+        const Draw& d = draws[di];
+        const Primitive& pr = c.prims[d.prim];
+        const int64_t ntri = (int64_t)(pr.idx.size() / 3);
+#pragma omp parallel for schedule(static) reduction(+ : n_binned)
+        for (int64_t t = 0; t < ntri; t++)
+            if (setup_triangle(d, pr, (size_t)t, W, H, S, cull, recs[first[di] + (size_t)t])) n_binned++;
+    }
+    if (tri_instances) *tri_instances += total;
+    if (tri_binned) *tri_binned += n_binned;
+
+    // phase 2: horizontal bands, so that threads never share a pixel and every
+    // pixel still sees the triangles in submission order
+    const int bands = std::max(1, std::min(128, H / 4));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int band = 0; band < bands; band++) {
+        const int by0 = (int)((int64_t)H * band / bands), by1 = (int)((int64_t)H * (band + 1) / bands) - 1;
+        FragmentSink* sink = rt.make_sink ? rt.make_sink(rt.sink_user, band) : nullptr;
+        for (size_t ri = 0; ri < total; ri++) {
+            const SetupRec& r = recs[ri];
+            if (r.n == 0 || r.iy1 < by0 || r.iy0 > by1) continue;
+            const int n = r.n;
+            int64_t eA[9], eB[9];
+            int bias[9];
+            for (int i = 0; i < n; i++) {
+                const int j = (i + 1) % n;
+                const int32_t dX = r.X[j] - r.X[i], dY = r.Y[j] - r.Y[i];
+                eA[i] = dX; eB[i] = dY;
+                const bool topleft = (dY < 0) || (dY == 0 && dX > 0);
+                bias[i] = topleft ? 0 : 1;
+            }
+            const int y_lo = std::max(r.iy0, by0), y_hi = std::min(r.iy1, by1);
+            for (int py = y_lo; py <= y_hi; py++)
+                for (int px = r.ix0; px <= r.ix1; px++)
+                    for (int s = 0; s < S; s++) {
+                        const int64_t Px = 256 * (int64_t)px + (S == 1 ? 128 : kSampleX4[s]);
+                        const int64_t Py = 256 * (int64_t)py + (S == 1 ? 128 : kSampleY4[s]);
+                        bool inside = true;
+                        for (int i = 0; i < n && inside; i++) {
+                            const int64_t E = eA[i] * (Py - r.Y[i]) - eB[i] * (Px - r.X[i]);
+                            inside = E >= bias[i];
+                        }
+                        if (!inside) continue;
+                        float z = (float)std::fma(r.dzdX, (double)Px, std::fma(r.dzdY, (double)Py, r.z00));
+                        z = z < 0.0f ? 0.0f : (z > 1.0f ? 1.0f : z);
+                        const size_t o = ((size_t)s * H + py) * W + px;
+                        if (z < rt.depth[o]) {  // depth test LESS, depth write on
+                            rt.depth[o] = z;
+                            if (rt.vis) rt.vis[o] = r.id;
+                            if (sink) sink->fragment(px, py, s, r.id);
+                        }
+                    }
+        }
+        delete sink;
+    }
+}
+
+}  // namespace orc
