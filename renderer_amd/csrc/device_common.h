@@ -1,0 +1,178 @@
+// Device-side helpers shared by the kernels: storage-format conversions,
+// exact transforms, texture/cube/shadow sampling.
+//
+// Files that include this header are compiled with -ffp-contract=off: every
+// fused multiply-add is written out as fmaf()/fma(), and float '/' and sqrtf
+// are IEEE correctly rounded (hipcc default). That makes the values that feed
+// discontinuous decisions (coverage, depth, shadow compares) independent of
+// the compiler's instruction selection.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rdr_device.h"
+
+#define RDR_DEV __device__ __forceinline__
+
+struct F3 { float x, y, z; };
+struct F4 { float x, y, z, w; };
+
+RDR_DEV F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+RDR_DEV F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RDR_DEV F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RDR_DEV F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+RDR_DEV float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RDR_DEV F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+// v * (1 / sqrt(dot(v,v))) with correctly rounded sqrt and divide
+RDR_DEV F3 normalize3(F3 a) { const float s = 1.0f / sqrtf(dot3(a, a)); return a * s; }
+RDR_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// m is column-major: m[col*4+row]
+RDR_DEV F4 xform_point(const float* m, float x, float y, float z) {
+    F4 r;
+    r.x = fmaf(m[0], x, fmaf(m[4], y, fmaf(m[8], z, m[12])));
+    r.y = fmaf(m[1], x, fmaf(m[5], y, fmaf(m[9], z, m[13])));
+    r.z = fmaf(m[2], x, fmaf(m[6], y, fmaf(m[10], z, m[14])));
+    r.w = fmaf(m[3], x, fmaf(m[7], y, fmaf(m[11], z, m[15])));
+    return r;
+}
+RDR_DEV F3 xform_dir(const float* m, float x, float y, float z) {
+    return f3(fmaf(m[0], x, fmaf(m[4], y, m[8] * z)), fmaf(m[1], x, fmaf(m[5], y, m[9] * z)), fmaf(m[2], x, fmaf(m[6], y, m[10] * z)));
+}
+
+// ---- float16 (colour attachment R16G16B16A16_SFLOAT), round to nearest even
+RDR_DEV uint32_t f32_to_f16_bits(float f) { const _Float16 h = (_Float16)f; unsigned short u; __builtin_memcpy(&u, &h, 2); return (uint32_t)u; }
+RDR_DEV float f16_bits_to_f32(uint32_t b) { const unsigned short u = (unsigned short)b; _Float16 h; __builtin_memcpy(&h, &u, 2); return (float)h; }
+RDR_DEV float quantize_half(float f) { return f16_bits_to_f32(f32_to_f16_bits(f)); }
+RDR_DEV uint2 pack_half4(float r, float g, float b, float a) {
+    return make_uint2(f32_to_f16_bits(r) | (f32_to_f16_bits(g) << 16), f32_to_f16_bits(b) | (f32_to_f16_bits(a) << 16));
+}
+RDR_DEV void unpack_half4(uint2 p, float& r, float& g, float& b, float& a) {
+    r = f16_bits_to_f32(p.x & 0xFFFFu); g = f16_bits_to_f32(p.x >> 16);
+    b = f16_bits_to_f32(p.y & 0xFFFFu); a = f16_bits_to_f32(p.y >> 16);
+}
+
+// ---- B10G11R11_UFLOAT: 5 exponent bits, MB mantissa bits, no sign. Negative
+// -> 0, NaN -> NaN, +inf -> inf, above the largest finite -> largest finite,
+// mantissa truncated, denormals kept.
+template <int MB> RDR_DEV uint32_t float_to_ufloat(float f) {
+    const uint32_t x = __float_as_uint(f);
+    const uint32_t max_finite = (30u << MB) | ((1u << MB) - 1u);
+    if ((x & 0x7FFFFFFFu) > 0x7F800000u) return (31u << MB) | 1u;
+    if (x & 0x80000000u) return 0u;
+    if (x == 0x7F800000u) return 31u << MB;
+    const int e = (int)(x >> 23) - 127;
+    const uint32_t m = x & 0x7FFFFFu;
+    if (e > 15) return max_finite;
+    if (e >= -14) return ((uint32_t)(e + 15) << MB) | (m >> (23 - MB));
+    const int shift = (23 - MB) + (-14 - e);
+    if (shift > 24) return 0u;
+    return (m | 0x800000u) >> shift;
+}
+template <int MB> RDR_DEV float ufloat_to_float(uint32_t v) {
+    const uint32_t e = v >> MB, m = v & ((1u << MB) - 1u);
+    if (e == 0) return (float)m * __uint_as_float((uint32_t)(127 - 14 - MB) << 23);
+    if (e == 31) return __uint_as_float(0x7F800000u | (m << (23 - MB)));
+    return __uint_as_float(((e + 112u) << 23) | (m << (23 - MB)));
+}
+RDR_DEV uint32_t pack_r11g11b10(float r, float g, float b) {
+    return float_to_ufloat<6>(r) | (float_to_ufloat<6>(g) << 11) | (float_to_ufloat<5>(b) << 22);
+}
+RDR_DEV void unpack_r11g11b10(uint32_t p, float& r, float& g, float& b) {
+    r = ufloat_to_float<6>(p & 0x7FFu);
+    g = ufloat_to_float<6>((p >> 11) & 0x7FFu);
+    b = ufloat_to_float<5>(p >> 22);
+}
+
+// UNORM8: clamp, scale, round half up; NaN -> 0
+RDR_DEV uint32_t float_to_unorm8(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 1.0f) return 255u;
+    return (uint32_t)(int)(f * 255.0f + 0.5f);
+}
+
+// ---- cube maps: Vulkan face selection (z wins ties over y over x), bilinear
+// inside the face with clamp-to-edge
+RDR_DEV int cube_face(float rx, float ry, float rz, float& s, float& t) {
+    const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+    int face; float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = rz < 0.0f ? 5 : 4; sc = rz < 0.0f ? -rx : rx; tc = -ry; ma = az; }
+    else if (ay >= ax) { face = ry < 0.0f ? 3 : 2; sc = rx; tc = ry < 0.0f ? -rz : rz; ma = ay; }
+    else { face = rx < 0.0f ? 1 : 0; sc = rx < 0.0f ? rz : -rz; tc = -ry; ma = ax; }
+    s = 0.5f * (sc / ma) + 0.5f;
+    t = 0.5f * (tc / ma) + 0.5f;
+    return face;
+}
+RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
+    float s, t;
+    const int face = cube_face(dx, dy, dz, s, t);
+    const uint32_t rr = cube.res >> level;
+    const int r = (int)(rr ? rr : 1u);
+    const uint32_t* px = cube.texels + cube.level_offset[level] + (size_t)face * r * r;
+    const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = min(max((int)fu, 0), r - 1), i1 = min(max((int)fu + 1, 0), r - 1);
+    const int j0 = min(max((int)fv, 0), r - 1), j1 = min(max((int)fv + 1, 0), r - 1);
+    const uint32_t q00 = px[j0 * r + i0], q10 = px[j0 * r + i1], q01 = px[j1 * r + i0], q11 = px[j1 * r + i1];
+    float c00[3], c10[3], c01[3], c11[3];
+    unpack_r11g11b10(q00, c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(q10, c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(q01, c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(q11, c11[0], c11[1], c11[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float top = (1.0f - a) * c00[k] + a * c10[k], bot = (1.0f - a) * c01[k] + a * c11[k];
+        out[k] = (1.0f - b) * top + b * bot;
+    }
+}
+
+// ---- 2D material textures: trilinear, isotropic LOD
+RDR_DEV int wrap_index(int i, int n, uint32_t mode) {
+    if (mode == 0u) { int r = i % n; return r < 0 ? r + n : r; }
+    if (mode == 1u) {
+        const int period = 2 * n;
+        int r = i % period; if (r < 0) r += period;
+        return r < n ? r : period - 1 - r;
+    }
+    return min(max(i, 0), n - 1);
+}
+RDR_DEV void tex_bilinear(const DFrame& fr, const DTexture& t, uint32_t level, float u, float v, float out[4]) {
+    const uint32_t ww = t.w >> level, hh = t.h >> level;
+    const int w = (int)(ww ? ww : 1u), h = (int)(hh ? hh : 1u);
+    const uint32_t* px = (const uint32_t*)t.base + t.level_offset[level];
+    const float tu = u * (float)w - 0.5f, tv = v * (float)h - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const uint32_t wu = (t.flags >> 4) & 3u, wv = (t.flags >> 8) & 3u;
+    const int i0 = wrap_index((int)fu, w, wu), i1 = wrap_index((int)fu + 1, w, wu);
+    const int j0 = wrap_index((int)fv, h, wv), j1 = wrap_index((int)fv + 1, h, wv);
+    const uint32_t q00 = px[j0 * w + i0], q10 = px[j0 * w + i1], q01 = px[j1 * w + i0], q11 = px[j1 * w + i1];
+    const float* rgb = (t.flags & 1u) ? fr.srgb_decode : fr.unorm_decode;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float* tab = k < 3 ? rgb : fr.unorm_decode;
+        const float t00 = tab[(q00 >> (8 * k)) & 255u], t10 = tab[(q10 >> (8 * k)) & 255u];
+        const float t01 = tab[(q01 >> (8 * k)) & 255u], t11 = tab[(q11 >> (8 * k)) & 255u];
+        const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
+        out[k] = (1.0f - b) * top + b * bot;
+    }
+}
+RDR_DEV void tex_sample(const DFrame& fr, uint32_t tex, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4]) {
+    const DTexture& t = fr.textures[tex];
+    float lambda = 0.0f;
+    if (t.levels > 1u) {
+        const float ax = dudx * (float)t.w, ay = dvdx * (float)t.h, bx = dudy * (float)t.w, by = dvdy * (float)t.h;
+        const float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+        if (rho > 1.0f) lambda = fminf(__log2f(rho), (float)(t.levels - 1u));
+    }
+    if (!(lambda > 0.0f)) { tex_bilinear(fr, t, 0, u, v, out); return; }
+    const float fl = floorf(lambda);
+    const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, t.levels - 1u);
+    const float f = lambda - fl;
+    float c0[4], c1[4];
+    tex_bilinear(fr, t, l0, u, v, c0);
+    tex_bilinear(fr, t, l1, u, v, c1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (1.0f - f) * c0[k] + f * c1[k];
+}

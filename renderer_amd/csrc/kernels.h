@@ -1,0 +1,53 @@
+// Host-callable launchers of the HIP kernels. Every launcher only enqueues
+// work on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rdr_device.h"
+
+struct IrradianceTables {  // sin/cos of the 24 azimuth and 6 polar angles of envbakediffuse.frag:18-26
+    float cos_phi[24], sin_phi[24], sin_theta[6], cos_theta[6];
+};
+
+// kernels_post.hip
+void launch_hdr_to_bloom0(hipStream_t s, const void* hdr, uint32_t* bloom0, uint32_t n);
+void launch_bloom_down(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int dst_pitch);
+void launch_bloom_up(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int dst_pitch);
+void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* bloom0, uint32_t* out, float* loglum, uint32_t n, float scale,
+                    float inv_gamma, float white, float log2_6);
+void launch_average_luminance(hipStream_t s, const float* loglum, int W, int H, float* l16, float* l1);
+
+// kernels_sort.hip
+size_t scan_scratch_words(uint32_t n);
+void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch, uint32_t* d_total);
+uint32_t sort_chunks(uint32_t n);
+size_t sort_hist_words(uint32_t n);
+int launch_radix_sort(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, uint32_t key_bits, uint32_t* hist,
+                      uint32_t* scan_scratch, uint32_t* d_dummy_total);
+
+// kernels_raster.hip
+void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const uint32_t* draw_first, uint32_t n_draws, uint32_t n_inst,
+                  const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned);
+void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const uint32_t* pair_offset, uint32_t n_inst, uint32_t n_pairs,
+                 uint32_t* keys, uint32_t* vals);
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles,
+                   uint32_t* n_valid);
+void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
+                   const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, bool any_s1, bool any_s4);
+
+// kernels_shade.hip
+void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws,
+                         const float* depth, const uint32_t* vis, void* hdr, void* samples_out, uint32_t W, uint32_t H);
+void launch_resolve4(hipStream_t s, const void* samples, void* hdr, uint32_t n);
+void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* views, const DDraw* draws, const uint32_t* first_tri,
+                         uint32_t n_draws, const DTriRec* recs, const uint32_t* sorted_vals, const uint32_t* tile_start,
+                         const uint32_t* tile_end, uint32_t n_tiles, void* color);
+
+// kernels_ibl.hip
+void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n);
+void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb);
+void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig);
+void launch_mip_blit(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int srgb, const float* srgb_decode,
+                     const float* unorm_decode, const float* thr);

@@ -1,0 +1,168 @@
+// One-off resource kernels: environment cube upload (RGBA32F -> B10G11R11),
+// irradiance and GGX-prefilter bakes, and material-texture mip generation.
+//
+// Reference: Renderer/VulkanRendererEnvironment.cpp:71-125 (upload/convert),
+// :193-250 + shaders/envbakediffuse.frag (irradiance, 256^2 per face),
+// :324-391 + shaders/envbakespecular.frag (prefilter, 512^2, 10 levels,
+// roughness = level/9), shaders/envbake.vert (direction per pixel);
+// Renderer/VulkanRenderer.cpp:332-340 (mip chain by linear blits).
+//
+// These run once per scene, so they are written for exact agreement with the
+// CPU checker rather than speed: correctly rounded divide/sqrt, no
+// contraction, and the trigonometric values of the fixed sample angles come
+// from host tables.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_env_pack(const float4* __restrict__ face, uint32_t* __restrict__ dst, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = face[i];
+    dst[i] = pack_r11g11b10(c.x, c.y, c.z);
+}
+
+// envbake.vert with the face rotations of VulkanRendererEnvironment.cpp:209-217 written out
+RDR_DEV F3 bake_direction(int face, int x, int y, int res) {
+    const float xn = ((float)x + 0.5f) * (2.0f / (float)res) - 1.0f;
+    const float yn = ((float)y + 0.5f) * (2.0f / (float)res) - 1.0f;
+    const float vx = xn, vy = -yn, vz = 1.0f;
+    switch (face) {
+        case 0: return f3(vz, vy, -vx);
+        case 1: return f3(-vz, vy, vx);
+        case 2: return f3(vx, vz, -vy);
+        case 3: return f3(vx, -vz, vy);
+        case 4: return f3(vx, vy, vz);
+        default: return f3(-vx, vy, -vz);
+    }
+}
+
+// envbakediffuse.frag:12-40
+__global__ void __launch_bounds__(256) k_bake_irradiance(DCube env, uint32_t* __restrict__ dst, int res, IrradianceTables tb) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= 6u * res * res) return;
+    const int face = (int)(i / (uint32_t)(res * res)), y = (int)((i / (uint32_t)res) % (uint32_t)res), x = (int)(i % (uint32_t)res);
+    const float PI = 3.14159265359f;
+    const int nSamples = 24;
+    const F3 normal = normalize3(bake_direction(face, x, y, res));
+    F3 up = f3(0.0f, 1.0f, 0.0f);
+    const F3 right = normalize3(cross3(up, normal));
+    up = normalize3(cross3(normal, right));
+    float irr[3] = {0.0f, 0.0f, 0.0f};
+    for (int a = 0; a < nSamples; a++)
+        for (int b = 0; b < nSamples / 4; b++) {
+            const float st = tb.sin_theta[b], ct = tb.cos_theta[b];
+            const float tx = st * tb.cos_phi[a], ty = st * tb.sin_phi[a], tz = ct;
+            const F3 sv = right * tx + up * ty + normal * tz;
+            float e[3];
+            cube_sample(env, 0, sv.x, sv.y, sv.z, e);
+#pragma unroll
+            for (int k = 0; k < 3; k++) irr[k] += e[k] * ct * st;
+        }
+    const float norm = 1.0f / (float)(nSamples * nSamples / 4);
+#pragma unroll
+    for (int k = 0; k < 3; k++) irr[k] = PI * irr[k] * norm;
+    dst[i] = pack_r11g11b10(irr[0], irr[1], irr[2]);
+}
+
+RDR_DEV float radical_inverse(uint32_t bits) {
+    bits = (bits << 16u) | (bits >> 16u);
+    bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
+    bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
+    bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
+    bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+    return (float)bits * 2.3283064365386963e-10f;
+}
+
+// envbakespecular.frag:32-86; cos/sin of phi_i = 2 pi i/128 come from `trig` (256 floats: cos then sin)
+__global__ void __launch_bounds__(256) k_bake_prefilter(DCube env, uint32_t* __restrict__ dst, int res, float roughness,
+                                                        const float* __restrict__ trig) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= 6u * res * res) return;
+    const int face = (int)(i / (uint32_t)(res * res)), y = (int)((i / (uint32_t)res) % (uint32_t)res), x = (int)(i % (uint32_t)res);
+    const int nSamples = 128;
+    const F3 N = normalize3(bake_direction(face, x, y, res));
+    const F3 V = N;
+    float col[3] = {0.0f, 0.0f, 0.0f}, total = 0.0f;
+    const float a = roughness * roughness;
+    const F3 upv = fabsf(N.z) < 0.999f ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
+    const F3 tangent = normalize3(cross3(upv, N));
+    const F3 bitangent = cross3(N, tangent);
+    for (int s = 0; s < nSamples; s++) {
+        const float xi_y = radical_inverse((uint32_t)s);
+        const float cosTheta = sqrtf((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float hx = trig[s] * sinTheta, hy = trig[128 + s] * sinTheta, hz = cosTheta;
+        const F3 H = normalize3(tangent * hx + bitangent * hy + N * hz);
+        const F3 L = normalize3(H * (2.0f * dot3(V, H)) - V);
+        const float NdotL = fmaxf(dot3(N, L), 0.0f);
+        if (NdotL > 0.0f) {
+            float e[3];
+            cube_sample(env, 0, L.x, L.y, L.z, e);
+#pragma unroll
+            for (int k = 0; k < 3; k++) col[k] += e[k] * NdotL;
+            total += NdotL;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) col[k] /= total;
+    dst[i] = pack_r11g11b10(col[0], col[1], col[2]);
+}
+
+// vkCmdBlitImage(LINEAR) from one mip level to the next; sRGB images are
+// filtered in linear light. `thr` = 256 encode thresholds (linear value of code n + 0.5).
+__global__ void __launch_bounds__(256) k_mip_blit(const uint32_t* __restrict__ src, int sw, int sh, uint32_t* __restrict__ dst, int dw, int dh,
+                                                  int srgb, const float* __restrict__ srgb_decode, const float* __restrict__ unorm_decode,
+                                                  const float* __restrict__ thr) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)(dw * dh)) return;
+    const int x = (int)(i % (uint32_t)dw), y = (int)(i / (uint32_t)dw);
+    const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+    const float u = ((float)x + 0.5f) * scale_x - 0.5f, v = ((float)y + 0.5f) * scale_y - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const int i0 = min(max((int)fu, 0), sw - 1), i1 = min(max((int)fu + 1, 0), sw - 1);
+    const int j0 = min(max((int)fv, 0), sh - 1), j1 = min(max((int)fv + 1, 0), sh - 1);
+    const uint32_t q00 = src[j0 * sw + i0], q10 = src[j0 * sw + i1], q01 = src[j1 * sw + i0], q11 = src[j1 * sw + i1];
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool lin = srgb && k < 3;
+        const float* tab = lin ? srgb_decode : unorm_decode;
+        const float t00 = tab[(q00 >> (8 * k)) & 255u], t10 = tab[(q10 >> (8 * k)) & 255u];
+        const float t01 = tab[(q01 >> (8 * k)) & 255u], t11 = tab[(q11 >> (8 * k)) & 255u];
+        const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
+        const float r = (1.0f - b) * top + b * bot;
+        uint32_t code;
+        if (lin) {
+            if (!(r > 0.0f)) code = 0;
+            else {
+                int lo = 0, hi = 255;  // number of thresholds <= r among codes 0..254
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (r < thr[mid]) hi = mid; else lo = mid + 1;
+                }
+                code = (uint32_t)lo;
+            }
+        } else code = float_to_unorm8(r);
+        o |= code << (8 * k);
+    }
+    dst[i] = o;
+}
+
+}  // namespace
+
+void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n) {
+    hipLaunchKernelGGL(k_env_pack, dim3((n + 255) / 256), dim3(256), 0, s, (const float4*)face_rgba32f, dst, n);
+}
+void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb) {
+    hipLaunchKernelGGL(k_bake_irradiance, dim3((6u * res * res + 255) / 256), dim3(256), 0, s, env, dst, res, tb);
+}
+void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig) {
+    hipLaunchKernelGGL(k_bake_prefilter, dim3((6u * res * res + 255) / 256), dim3(256), 0, s, env, dst, res, roughness, trig);
+}
+void launch_mip_blit(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int srgb, const float* srgb_decode,
+                     const float* unorm_decode, const float* thr) {
+    hipLaunchKernelGGL(k_mip_blit, dim3((dw * dh + 255) / 256), dim3(256), 0, s, src, sw, sh, dst, dw, dh, srgb, srgb_decode, unorm_decode, thr);
+}

@@ -1,0 +1,362 @@
+// Software rasteriser: replaces the fixed-function half of the reference's
+// depth-tested triangle-list draws (pipeline state:
+// Renderer/VulkanRenderer.cpp:836-866 main pass,
+// Renderer/VulkanRendererShadow.cpp:72-118 shadow passes; vertex stage:
+// Renderer/shaders/shadowmap.vert:10-12, basic.vert:37).
+//
+//   k_setup   one thread per triangle instance: transform, clip to a polygon
+//             (near, far, +-16384 px guard band), snap to 1/256 px, facing +
+//             cull, pixel/tile bounding box, depth plane   -> DTriRec
+//   k_emit    one thread per (triangle, tile) candidate: exact tile test,
+//             key = global tile id                        -> pairs
+//   (stable radix sort of the pairs by tile: kernels_sort.hip)
+//   k_ranges  list boundaries per tile
+//   k_raster  one 256-thread block per 16x16 tile, one wave per 8x8 quadrant:
+//             records staged through LDS 64 at a time, each wave ballots the
+//             records whose box touches its quadrant and walks the set bits in
+//             order; edge functions are exact 64-bit integers, depth is a
+//             double-precision plane rounded to float, test LESS.
+//
+// Bit-exactness with the CPU checker rests on three things: the fma chains
+// are written out, the edge functions are integer, and double arithmetic is
+// IEEE on both sides. This file must be compiled with -ffp-contract=off.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace {
+
+struct ClipV { float x, y, z, w; };
+
+RDR_DEV float plane_dist(const ClipV& v, int plane, float kx, float ky) {
+    switch (plane) {
+        case 0: return v.z;
+        case 1: return v.w - v.z;
+        case 2: return fmaf(kx, v.w, v.x);
+        case 3: return fmaf(kx, v.w, -v.x);
+        case 4: return fmaf(ky, v.w, v.y);
+        default: return fmaf(ky, v.w, -v.y);
+    }
+}
+
+RDR_DEV uint32_t find_draw(const uint32_t* __restrict__ draw_first, uint32_t n_draws, uint32_t inst) {
+    uint32_t lo = 0, hi = n_draws;  // largest d with draw_first[d] <= inst
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (draw_first[mid] <= inst) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, const DDraw* __restrict__ draws,
+                                               const uint32_t* __restrict__ draw_first, uint32_t n_draws, uint32_t n_inst,
+                                               const DPrim* __restrict__ prims, const float4* __restrict__ pos,
+                                               const uint32_t* __restrict__ idx, DTriRec* __restrict__ recs,
+                                               uint32_t* __restrict__ pair_count, uint32_t* __restrict__ n_binned) {
+    const uint32_t inst = blockIdx.x * 256u + threadIdx.x;
+    if (inst >= n_inst) return;
+    const uint32_t di = find_draw(draw_first, n_draws, inst);
+    const DDraw& d = draws[di];
+    const DView& vw = views[d.view];
+    const DPrim& pr = prims[d.prim];
+    const uint32_t tri = inst - d.first_instance;
+    DTriRec& rec = recs[inst];
+    uint32_t count = 0;
+    rec.n_view = 0;
+    do {
+        const uint32_t* ip = idx + pr.first_index + 3u * tri;
+        const float4 p0 = pos[pr.first_vertex + ip[0]], p1 = pos[pr.first_vertex + ip[1]], p2 = pos[pr.first_vertex + ip[2]];
+        ClipV cv[3];
+        {
+            const F4 a = xform_point(d.mvp, p0.x, p0.y, p0.z), b = xform_point(d.mvp, p1.x, p1.y, p1.z), c = xform_point(d.mvp, p2.x, p2.y, p2.z);
+            cv[0] = {a.x, a.y, a.z, a.w}; cv[1] = {b.x, b.y, b.z, b.w}; cv[2] = {c.x, c.y, c.z, c.w};
+        }
+        bool finite = true;
+#pragma unroll
+        for (int i = 0; i < 3; i++) finite = finite && isfinite(cv[i].x) && isfinite(cv[i].y) && isfinite(cv[i].z) && isfinite(cv[i].w);
+        if (!finite) break;
+        const int W = (int)vw.w, H = (int)vw.h, S = (int)vw.samples;
+        const float kx = 32768.0f / (float)W, ky = 32768.0f / (float)H;
+        const float halfW256 = 128.0f * (float)W, halfH256 = 128.0f * (float)H;
+
+        // ---- clip: a plane is applied only if an input vertex lies outside it
+        uint32_t need = 0;
+        bool rejected = false;
+#pragma unroll
+        for (int plane = 0; plane < 6; plane++) {
+            int outside = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) outside += plane_dist(cv[i], plane, kx, ky) < 0.0f ? 1 : 0;
+            if (outside == 3) rejected = true;
+            if (outside) need |= 1u << plane;
+        }
+        if (rejected) break;
+        int32_t X[RDR_MAX_POLY], Y[RDR_MAX_POLY];
+        int n = 3;
+        bool ok = true;
+        if (need == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const float xn = cv[i].x / cv[i].w, yn = cv[i].y / cv[i].w;
+                const float fx = rintf(fmaf(xn, halfW256, halfW256)), fy = rintf(fmaf(yn, halfH256, halfH256));
+                if (!(fabsf(fx) <= 16777216.0f) || !(fabsf(fy) <= 16777216.0f)) ok = false;
+                X[i] = (int32_t)fx; Y[i] = (int32_t)fy;
+            }
+        } else {
+            ClipV poly[12], tmp[12];
+            poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2];
+            for (int plane = 0; plane < 6 && ok; plane++) {
+                if (!(need & (1u << plane))) continue;
+                int m = 0;
+                for (int i = 0; i < n; i++) {
+                    const ClipV a = poly[i];
+                    const ClipV b = poly[(i + 1) % n];
+                    const float da = plane_dist(a, plane, kx, ky), db = plane_dist(b, plane, kx, ky);
+                    const bool ina = da >= 0.0f, inb = db >= 0.0f;
+                    if (ina) tmp[m++] = a;
+                    if (ina != inb) {
+                        const ClipV in = ina ? a : b;
+                        const ClipV out = ina ? b : a;
+                        const float din = ina ? da : db, dout = ina ? db : da;
+                        const float tt = din / (din - dout);
+                        ClipV q;
+                        q.x = fmaf(tt, out.x - in.x, in.x);
+                        q.y = fmaf(tt, out.y - in.y, in.y);
+                        q.z = fmaf(tt, out.z - in.z, in.z);
+                        q.w = fmaf(tt, out.w - in.w, in.w);
+                        tmp[m++] = q;
+                    }
+                }
+                n = m;
+                for (int i = 0; i < n; i++) poly[i] = tmp[i];
+                if (n < 3) ok = false;
+            }
+            if (n > RDR_MAX_POLY) ok = false;
+            if (ok) {
+                for (int i = 0; i < n; i++) {
+                    const float xn = poly[i].x / poly[i].w, yn = poly[i].y / poly[i].w;
+                    const float fx = rintf(fmaf(xn, halfW256, halfW256)), fy = rintf(fmaf(yn, halfH256, halfH256));
+                    if (!(fabsf(fx) <= 16777216.0f) || !(fabsf(fy) <= 16777216.0f)) ok = false;
+                    X[i] = (int32_t)fx; Y[i] = (int32_t)fy;
+                }
+            }
+        }
+        if (!ok) break;
+
+        // ---- facing: Vulkan area a = -1/2 sum(x_i y_i+1 - x_i+1 y_i), CCW front => front iff sum < 0
+        long long area2 = 0;
+        for (int i = 0; i < n; i++) {
+            const int j = (i + 1 == n) ? 0 : i + 1;
+            area2 += (long long)X[i] * Y[j] - (long long)X[j] * Y[i];
+        }
+        if (area2 == 0) break;
+        const bool front = area2 < 0;
+        if ((vw.cull == 2u && !front) || (vw.cull == 1u && front)) break;
+
+        // ---- pixel bounding box
+        int32_t minX = X[0], maxX = X[0], minY = Y[0], maxY = Y[0];
+        for (int i = 1; i < n; i++) {
+            minX = min(minX, X[i]); maxX = max(maxX, X[i]);
+            minY = min(minY, Y[i]); maxY = max(maxY, Y[i]);
+        }
+        int ix0, ix1, iy0, iy1;
+        if (S == 1) { ix0 = (minX - 128 + 255) >> 8; ix1 = (maxX - 128) >> 8; iy0 = (minY - 128 + 255) >> 8; iy1 = (maxY - 128) >> 8; }
+        else { ix0 = minX >> 8; ix1 = maxX >> 8; iy0 = minY >> 8; iy1 = maxY >> 8; }
+        ix0 = max(ix0, 0); iy0 = max(iy0, 0);
+        ix1 = min(ix1, W - 1); iy1 = min(iy1, H - 1);
+        if (ix0 > ix1 || iy0 > iy1) break;
+
+        // ---- depth plane a x + b y + c w = z through the unclipped vertices
+        const double x0 = cv[0].x, y0 = cv[0].y, z0 = cv[0].z, w0 = cv[0].w;
+        const double x1 = cv[1].x, y1 = cv[1].y, z1 = cv[1].z, w1 = cv[1].w;
+        const double x2 = cv[2].x, y2 = cv[2].y, z2 = cv[2].z, w2 = cv[2].w;
+        const double m_yw = y1 * w2 - y2 * w1, m_xw = x1 * w2 - x2 * w1, m_xy = x1 * y2 - x2 * y1;
+        const double m_zw = z1 * w2 - z2 * w1, m_zy = z1 * y2 - z2 * y1, m_xz = x1 * z2 - x2 * z1;
+        const double m_yz = y1 * z2 - y2 * z1;
+        const double det = (x0 * m_yw - y0 * m_xw) + w0 * m_xy;
+        if (det == 0.0 || !isfinite(det)) break;
+        const double pa = ((z0 * m_yw - y0 * m_zw) + w0 * m_zy) / det;
+        const double pb = ((x0 * m_zw - z0 * m_xw) + w0 * m_xz) / det;
+        const double pc = ((x0 * m_yz - y0 * m_xz) + z0 * m_xy) / det;
+        const double sx = 2.0 / (256.0 * (double)W), sy = 2.0 / (256.0 * (double)H);
+        const double dzdX = pa * sx, dzdY = pb * sy, z00 = (pc - pa) - pb;
+        if (!isfinite(dzdX) || !isfinite(dzdY) || !isfinite(z00)) break;
+
+        // ---- write the record, oriented so that the interior has positive edge functions
+        if (area2 < 0) { for (int i = 0; i < n; i++) { rec.X[i] = X[n - 1 - i]; rec.Y[i] = Y[n - 1 - i]; } }
+        else { for (int i = 0; i < n; i++) { rec.X[i] = X[i]; rec.Y[i] = Y[i]; } }
+        rec.id = d.first_tri_id + tri;
+        rec.px0 = (int16_t)ix0; rec.py0 = (int16_t)iy0; rec.px1 = (int16_t)ix1; rec.py1 = (int16_t)iy1;
+        rec.dzdX = dzdX; rec.dzdY = dzdY; rec.z00 = z00;
+        rec.n_view = (uint32_t)n | (d.view << 8);
+        count = (uint32_t)((ix1 / RDR_TILE - ix0 / RDR_TILE + 1) * (iy1 / RDR_TILE - iy0 / RDR_TILE + 1));
+    } while (false);
+    pair_count[inst] = count;
+    if (count) atomicAdd(n_binned, 1u);
+}
+
+// One thread per candidate pair. pair_offset is the exclusive scan of pair_count.
+__global__ void __launch_bounds__(256) k_emit(const DView* __restrict__ views, const DTriRec* __restrict__ recs,
+                                              const uint32_t* __restrict__ pair_offset, uint32_t n_inst, uint32_t n_pairs,
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_pairs) return;
+    uint32_t lo = 0, hi = n_inst;  // largest i with pair_offset[i] <= p
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pair_offset[mid] <= p) lo = mid; else hi = mid;
+    }
+    const DTriRec& r = recs[lo];
+    const uint32_t local = p - pair_offset[lo];
+    const int n = (int)(r.n_view & 255u);
+    const DView& vw = views[r.n_view >> 8];
+    const int tx0 = r.px0 / RDR_TILE, ty0 = r.py0 / RDR_TILE, tx1 = r.px1 / RDR_TILE;
+    const int bw = tx1 - tx0 + 1;
+    const int tx = tx0 + (int)(local % (uint32_t)bw), ty = ty0 + (int)(local / (uint32_t)bw);
+    // sample-position extent of the part of the tile inside the triangle's pixel box
+    const int bx0 = max(tx * RDR_TILE, (int)r.px0), bx1 = min(tx * RDR_TILE + RDR_TILE - 1, (int)r.px1);
+    const int by0 = max(ty * RDR_TILE, (int)r.py0), by1 = min(ty * RDR_TILE + RDR_TILE - 1, (int)r.py1);
+    const int lo_off = vw.samples == 1u ? 128 : 32, hi_off = vw.samples == 1u ? 128 : 224;
+    const long long xmin = 256ll * bx0 + lo_off, xmax = 256ll * bx1 + hi_off, ymin = 256ll * by0 + lo_off, ymax = 256ll * by1 + hi_off;
+    bool keep = true;
+    for (int i = 0; i < n; i++) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        const long long dX = r.X[j] - r.X[i], dY = r.Y[j] - r.Y[i];
+        const long long Px = dY > 0 ? xmin : xmax, Py = dX > 0 ? ymax : ymin;  // corner where the edge function is largest
+        const long long E = dX * (Py - r.Y[i]) - dY * (Px - r.X[i]);
+        const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+        if (E < bias) keep = false;
+    }
+    keys[p] = keep ? vw.tile_base + (uint32_t)ty * vw.tiles_x + (uint32_t)tx : RDR_PAIR_INVALID;
+    vals[p] = lo;
+}
+
+__global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ keys, uint32_t n_pairs, uint32_t* __restrict__ tile_start,
+                                                uint32_t* __restrict__ tile_end, uint32_t* __restrict__ n_valid) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t k = keys[p];
+    const uint32_t prev = p ? keys[p - 1] : RDR_PAIR_INVALID;
+    if (k != prev || p == 0) {
+        if (k != RDR_PAIR_INVALID) tile_start[k] = p;
+        if (p && prev != RDR_PAIR_INVALID) tile_end[prev] = p;
+        if (k == RDR_PAIR_INVALID) n_valid[0] = p;
+    }
+    if (p == n_pairs - 1 && k != RDR_PAIR_INVALID) { tile_end[k] = n_pairs; n_valid[0] = n_pairs; }
+}
+
+#define RASTER_CHUNK 64
+
+template <int S>
+__global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views, uint32_t n_views, const DTriRec* __restrict__ recs,
+                                                const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
+                                                const uint32_t* __restrict__ tile_end, uint32_t first_view, uint32_t tile_origin) {
+    __shared__ uint32_t lds_rec[RASTER_CHUNK * 32];  // 64 records of 128 bytes
+    __shared__ uint32_t lds_ids[RASTER_CHUNK];
+    const uint32_t tile = tile_origin + blockIdx.x;
+    // view of this tile: largest v with tile_base <= tile (views are few; block-uniform loop)
+    uint32_t v = first_view;
+    for (uint32_t k = first_view + 1; k < n_views; k++) if (views[k].tile_base <= tile) v = k;
+    const DView vw = views[v];
+    if ((S == 4) != (vw.samples == 4u)) return;  // the other instantiation handles it
+    const uint32_t local_tile = tile - vw.tile_base;
+    if (local_tile >= vw.tiles_x * vw.tiles_y) return;
+    const int tx = (int)(local_tile % vw.tiles_x), ty = (int)(local_tile / vw.tiles_x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qx0 = tx * RDR_TILE + (wave & 1) * 8, qy0 = ty * RDR_TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool in_view = px < (int)vw.w && py < (int)vw.h;
+    const size_t plane_px = (size_t)vw.w * vw.h;
+    const size_t o = (size_t)py * vw.w + px;
+
+    float z[S];
+    uint32_t id[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        z[s] = (vw.load && in_view) ? vw.depth[s * plane_px + o] : 1.0f;
+        id[s] = RDR_PAIR_INVALID;
+    }
+    const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
+    const uint32_t begin = tile_start[tile], end = tile_end[tile];
+    bool touched = false;
+    for (uint32_t base = begin; base < end; base += RASTER_CHUNK) {
+        const uint32_t cnt = min((uint32_t)RASTER_CHUNK, end - base);
+        __syncthreads();
+        if (threadIdx.x < cnt) lds_ids[threadIdx.x] = sorted_vals[base + threadIdx.x];
+        __syncthreads();
+        // 32 consecutive threads copy one 128-byte record
+        for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += 256u)
+            lds_rec[dw] = ((const uint32_t*)(recs + lds_ids[dw >> 5]))[dw & 31u];
+        __syncthreads();
+        // lane l of each wave looks at record l: does its pixel box touch this wave's 8x8 quadrant?
+        bool hit = false;
+        if ((uint32_t)lane < cnt) {
+            const DTriRec* r = (const DTriRec*)(lds_rec + lane * 32);
+            hit = r->px0 <= qx0 + 7 && r->px1 >= qx0 && r->py0 <= qy0 + 7 && r->py1 >= qy0;
+        }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int ri = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const DTriRec* r = (const DTriRec*)(lds_rec + ri * 32);
+            const int n = (int)(r->n_view & 255u);
+            const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
+            const uint32_t rid = r->id;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const int Px = 256 * px + (S == 1 ? 128 : sxo[s]), Py = 256 * py + (S == 1 ? 128 : syo[s]);
+                bool inside = true;
+                for (int i = 0; i < n; i++) {
+                    const int j = (i + 1 == n) ? 0 : i + 1;
+                    const int Xi = r->X[i], Yi = r->Y[i];
+                    const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                    const long long E = (long long)dX * (long long)(Py - Yi) - (long long)dY * (long long)(Px - Xi);
+                    const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+                    inside = inside && (E >= bias);
+                }
+                if (inside) {
+                    float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
+                    zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
+                    if (zz < z[s]) { z[s] = zz; id[s] = rid; }
+                }
+            }
+            touched = true;
+        }
+    }
+    if (!in_view) return;
+    if (!vw.load || touched) {
+#pragma unroll
+        for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = z[s];
+    }
+    if (vw.vis) {
+#pragma unroll
+        for (int s = 0; s < S; s++) vw.vis[s * plane_px + o] = id[s];
+    }
+}
+
+}  // namespace
+
+void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const uint32_t* draw_first, uint32_t n_draws, uint32_t n_inst,
+                  const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned) {
+    if (!n_inst) return;
+    hipLaunchKernelGGL(k_setup, dim3((n_inst + 255) / 256), dim3(256), 0, s, views, draws, draw_first, n_draws, n_inst, prims,
+                       (const float4*)pos, idx, recs, pair_count, n_binned);
+}
+void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const uint32_t* pair_offset, uint32_t n_inst, uint32_t n_pairs,
+                 uint32_t* keys, uint32_t* vals) {
+    if (!n_pairs) return;
+    hipLaunchKernelGGL(k_emit, dim3((n_pairs + 255) / 256), dim3(256), 0, s, views, recs, pair_offset, n_inst, n_pairs, keys, vals);
+}
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles,
+                   uint32_t* n_valid) {
+    (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 4, s);
+    (void)hipMemsetAsync(tile_end, 0, (size_t)n_tiles * 4, s);
+    (void)hipMemsetAsync(n_valid, 0, 4, s);
+    if (!n_pairs) return;
+    hipLaunchKernelGGL(k_ranges, dim3((n_pairs + 255) / 256), dim3(256), 0, s, keys, n_pairs, tile_start, tile_end, n_valid);
+}
+void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
+                   const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, bool any_s1, bool any_s4) {
+    if (!n_tiles) return;
+    if (any_s1) hipLaunchKernelGGL(k_raster<1>, dim3(n_tiles), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end, 0u, 0u);
+    if (any_s4) hipLaunchKernelGGL(k_raster<4>, dim3(n_tiles), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end, 0u, 0u);
+}

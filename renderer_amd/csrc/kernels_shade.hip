@@ -1,0 +1,469 @@
+// Main colour pass from the visibility buffer: basic.vert + pbr.frag per
+// pixel, the skybox (env.vert + env.frag), the in-order blended pass and the
+// multisample resolve.
+//
+// Reference: Renderer/shaders/basic.vert:36-49, pbr.frag:93-269, env.vert:22-26,
+// env.frag:10-17; pass order and blend state Renderer/VulkanRenderer.cpp:1043-1065,
+// :862-866.
+//
+// Layout: one thread per pixel, 256-thread blocks covering the same 16x16
+// tiles (8x8 per wave) as the rasteriser, so a wave's pixels share triangles,
+// materials and texture footprints. All scene data is read in place from HBM
+// (geometry arena, RGBA8 mip chains, packed-float cubes, D32F shadow arrays).
+//
+// Values that feed a discontinuous decision (shadow compares, cascade choice,
+// light cut-offs) are computed with correctly rounded operations in a fixed
+// order: barycentrics in double, world position and light-space coordinates
+// with explicit fma chains. The continuous BRDF math below them may use the
+// fast reciprocal / rsqrt / contraction.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace {
+
+RDR_DEV float interp3(const float lam[3], float a0, float a1, float a2) { return fmaf(lam[2], a2, fmaf(lam[1], a1, lam[0] * a0)); }
+
+RDR_DEV F3 fast_normalize(F3 a) { return a * __builtin_amdgcn_rsqf(dot3(a, a)); }
+RDR_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// sampler2DArrayShadow: LINEAR + compare LESS_OR_EQUAL + CLAMP_TO_BORDER(white) (VulkanRendererShadow.cpp:73)
+RDR_DEV float shadow_fetch(const float* __restrict__ map, int res, int i, int j, float ref) {
+    const float d = (i < 0 || j < 0 || i >= res || j >= res) ? 1.0f : map[(size_t)j * res + i];
+    return ref <= d ? 1.0f : 0.0f;
+}
+RDR_DEV float shadow_pcf(const float* __restrict__ map, int res, float s, float t, float ref) {
+    const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = (int)clampf(fu, -2.0f, (float)res + 1.0f), j0 = (int)clampf(fv, -2.0f, (float)res + 1.0f);
+    const float r00 = shadow_fetch(map, res, i0, j0, ref), r10 = shadow_fetch(map, res, i0 + 1, j0, ref);
+    const float r01 = shadow_fetch(map, res, i0, j0 + 1, ref), r11 = shadow_fetch(map, res, i0 + 1, j0 + 1, ref);
+    const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
+    return (1.0f - b) * top + b * bot;
+}
+// samplerCubeArrayShadow
+RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, float rz, float ref) {
+    const int res = (int)fr.point_res;
+    float s, t;
+    const int face = cube_face(rx, ry, rz, s, t);
+    const float* map = fr.point_shadow + ((size_t)slot * 6 + face) * res * res;
+    const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = min(max((int)fu, 0), res - 1), i1 = min(max((int)fu + 1, 0), res - 1);
+    const int j0 = min(max((int)fv, 0), res - 1), j1 = min(max((int)fv + 1, 0), res - 1);
+    const float r00 = ref <= map[j0 * res + i0] ? 1.0f : 0.0f, r10 = ref <= map[j0 * res + i1] ? 1.0f : 0.0f;
+    const float r01 = ref <= map[j1 * res + i0] ? 1.0f : 0.0f, r11 = ref <= map[j1 * res + i1] ? 1.0f : 0.0f;
+    const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
+    return (1.0f - b) * top + b * bot;
+}
+
+#define kPI 3.14159274f
+
+// pbr.frag:211-269. Continuous in all arguments: fast math allowed.
+RDR_DEV F3 brdf(F3 radiance, F3 L, F3 N, F3 V, F3 albedo, float roughness, float metallic, F3 F0) {
+#pragma clang fp contract(fast)
+    const F3 H = fast_normalize(V + L);
+    const float a = roughness * roughness, a2 = a * a;
+    const float NdotH = clampf(dot3(N, H), 0.0f, 1.0f);
+    float dd = NdotH * NdotH * (a2 - 1.0f) + 1.0f;
+    dd = kPI * dd * dd;
+    const float NDF = a2 * fast_rcp(dd);
+    const float r1 = roughness + 1.0f, k = (r1 * r1) * 0.125f;
+    const float NdotV1 = fmaxf(dot3(N, V), 0.001f), NdotL1 = fmaxf(dot3(N, L), 0.001f);
+    const float G = (NdotL1 * fast_rcp(NdotL1 * (1.0f - k) + k)) * (NdotV1 * fast_rcp(NdotV1 * (1.0f - k) + k));
+    const float x = 1.0f - clampf(fmaxf(dot3(H, V), 0.0f), 0.0f, 1.0f);
+    const float x2 = x * x, x5 = x2 * x2 * x;
+    const float inv_den = fast_rcp(fmaxf(4.0f * fmaxf(dot3(N, V), 1e-3f) * fmaxf(dot3(N, L), 1e-3f), 1e-5f));
+    const float NdotL = fmaxf(dot3(N, L), 0.0f);
+    const float Fx = F0.x + (1.0f - F0.x) * x5, Fy = F0.y + (1.0f - F0.y) * x5, Fz = F0.z + (1.0f - F0.z) * x5;
+    const float om = 1.0f - metallic, inv_pi = 1.0f / kPI;
+    F3 o;
+    o.x = ((1.0f - Fx) * om * albedo.x * inv_pi + NDF * G * Fx * inv_den) * radiance.x * NdotL;
+    o.y = ((1.0f - Fy) * om * albedo.y * inv_pi + NDF * G * Fy * inv_den) * radiance.y * NdotL;
+    o.z = ((1.0f - Fz) * om * albedo.z * inv_pi + NDF * G * Fz * inv_den) * radiance.z * NdotL;
+    return o;
+}
+
+// env.vert:22-26 + env.frag:10-17
+RDR_DEV void shade_sky(const DFrame& fr, int px, int py, float out[4]) {
+    const float xn = fmaf((float)px + 0.5f, fr.inv2W, -1.0f), yn = fmaf((float)py + 0.5f, fr.inv2H, -1.0f);
+    const float* m = fr.inv_viewproj;
+    F3 pos;
+    pos.x = fmaf(m[0], xn, fmaf(m[4], yn, m[8] + m[12]));
+    pos.y = fmaf(m[1], xn, fmaf(m[5], yn, m[9] + m[13]));
+    pos.z = fmaf(m[2], xn, fmaf(m[6], yn, m[10] + m[14]));
+    const F3 d = normalize3(pos);
+    float e[3] = {0.0f, 0.0f, 0.0f};
+    if (fr.env.res) cube_sample(fr.env, 0, d.x, d.y, d.z, e);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float v = e[k] / (e[k] + 1.0f);
+        out[k] = __powf(v, 1.0f / 2.2f);
+    }
+    out[3] = 1.0f;
+}
+
+// basic.vert for the triangle's three vertices + pbr.frag at the centre of pixel (px,py)
+__device__ __noinline__ void shade_fragment(const DFrame& fr, const DDraw& d, uint32_t tri, int px, int py, float out[4]) {
+    const DPrim& pr = fr.prims[d.prim];
+    const uint32_t* ip = fr.idx + pr.first_index + 3u * tri;
+    const uint32_t vi[3] = {pr.first_vertex + ip[0], pr.first_vertex + ip[1], pr.first_vertex + ip[2]};
+    float4 op[3];
+    F4 cp[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { op[k] = fr.pos[vi[k]]; cp[k] = xform_point(d.mvp, op[k].x, op[k].y, op[k].z); }
+
+    // ---- perspective-correct barycentrics (double) at (px,py), (px+1,py), (px,py+1)
+    double A[3], B[3], C[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const F4 p = cp[(k + 1) % 3], q = cp[(k + 2) % 3];
+        A[k] = (double)p.y * (double)q.w - (double)q.y * (double)p.w;
+        B[k] = (double)q.x * (double)p.w - (double)p.x * (double)q.w;
+        C[k] = (double)p.x * (double)q.y - (double)q.x * (double)p.y;
+    }
+    const float x0 = fmaf((float)px + 0.5f, fr.inv2W, -1.0f), x1 = fmaf((float)px + 1.5f, fr.inv2W, -1.0f);
+    const float y0 = fmaf((float)py + 0.5f, fr.inv2H, -1.0f), y1 = fmaf((float)py + 1.5f, fr.inv2H, -1.0f);
+    float lam[3][3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const double xn = e == 1 ? x1 : x0, yn = e == 2 ? y1 : y0;
+        double l[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) l[k] = fma(A[k], xn, fma(B[k], yn, C[k]));
+        const double sum = (l[0] + l[1]) + l[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) lam[e][k] = (float)(l[k] / sum);
+    }
+
+    // ---- vertex outputs
+    F3 wp[3], nrm[3], tan[3], bit[3];
+    float tu[3], tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const F4 w4 = xform_point(d.model, op[k].x, op[k].y, op[k].z);
+        wp[k] = w4.w == 1.0f ? f3(w4.x, w4.y, w4.z) : f3(w4.x / w4.w, w4.y / w4.w, w4.z / w4.w);
+        const DVertexAttr a = fr.attr[vi[k]];
+        nrm[k] = fast_normalize(xform_dir(d.model, a.nx, a.ny, a.nz));
+        tan[k] = fast_normalize(xform_dir(d.model, a.tx, a.ty, a.tz));
+        bit[k] = fast_normalize(xform_dir(d.model, a.bx, a.by, a.bz));
+        tu[k] = a.u; tv[k] = a.v;
+    }
+    const F3 P = f3(interp3(lam[0], wp[0].x, wp[1].x, wp[2].x), interp3(lam[0], wp[0].y, wp[1].y, wp[2].y), interp3(lam[0], wp[0].z, wp[1].z, wp[2].z));
+    const F3 Nv = f3(interp3(lam[0], nrm[0].x, nrm[1].x, nrm[2].x), interp3(lam[0], nrm[0].y, nrm[1].y, nrm[2].y), interp3(lam[0], nrm[0].z, nrm[1].z, nrm[2].z));
+    const F3 Tv = f3(interp3(lam[0], tan[0].x, tan[1].x, tan[2].x), interp3(lam[0], tan[0].y, tan[1].y, tan[2].y), interp3(lam[0], tan[0].z, tan[1].z, tan[2].z));
+    const F3 Bv = f3(interp3(lam[0], bit[0].x, bit[1].x, bit[2].x), interp3(lam[0], bit[0].y, bit[1].y, bit[2].y), interp3(lam[0], bit[0].z, bit[1].z, bit[2].z));
+    const float u0 = interp3(lam[0], tu[0], tu[1], tu[2]), v0 = interp3(lam[0], tv[0], tv[1], tv[2]);
+    const float dudx = interp3(lam[1], tu[0], tu[1], tu[2]) - u0, dvdx = interp3(lam[1], tv[0], tv[1], tv[2]) - v0;
+    const float dudy = interp3(lam[2], tu[0], tu[1], tu[2]) - u0, dvdy = interp3(lam[2], tv[0], tv[1], tv[2]) - v0;
+    const DMaterial& mt = pr.mat;
+
+    // ---- pbr.frag main()
+    float t[4];
+    tex_sample(fr, mt.tex[0] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[0], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    const float albedo[4] = {t[0] * mt.base_color[0], t[1] * mt.base_color[1], t[2] * mt.base_color[2], t[3] * mt.base_color[3]};
+    if (mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    tex_sample(fr, mt.tex[2] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[2], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    const float metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
+    const float roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
+    tex_sample(fr, mt.tex[3] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[3], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    const float ao = t[0] * mt.ao;
+    tex_sample(fr, mt.tex[4] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[4], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    const float emissive[3] = {t[0] * mt.emissive[0], t[1] * mt.emissive[1], t[2] * mt.emissive[2]};
+    tex_sample(fr, mt.tex[1] == 0xFFFFFFFFu ? fr.tex_normal : mt.tex[1], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
+    const float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f, nz = t[2] * 2.0f - 1.0f;
+    const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
+    const F3 cam = f3(fr.cam[0], fr.cam[1], fr.cam[2]);
+    const F3 V = fast_normalize(cam - P);
+    const F3 negV = V * -1.0f;
+    const F3 Rv = negV - N * (2.0f * dot3(N, negV));
+    const F3 alb = f3(albedo[0], albedo[1], albedo[2]);
+    const float om = 1.0f - metallic;
+    const F3 F0 = f3(0.04f * om + alb.x * metallic, 0.04f * om + alb.y * metallic, 0.04f * om + alb.z * metallic);
+    F3 Lo = f3(0.0f, 0.0f, 0.0f);
+
+    // ---- point lights (pbr.frag:123-160)
+    const float far = 100.0f, near = 0.1f;
+    for (uint32_t li = 0; li < fr.n_lights; li++) {
+        const DPointLight pl = fr.lights[li];
+        const F3 Lv = f3(pl.px, pl.py, pl.pz) - P;
+        const float dist = sqrtf(dot3(Lv, Lv));
+        const float attenuation = 1.0f / (dist * dist);
+        const F3 radiance = f3(pl.ix * attenuation, pl.iy * attenuation, pl.iz * attenuation);
+        if (fmaxf(radiance.x, fmaxf(radiance.y, radiance.z)) <= 1e-3f) continue;
+        float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
+        lightDepth = (far - far * near / lightDepth) / (far - near);
+        if ((pl.flags & 1u) && (pl.flags & 2u)) {
+            const float shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, lightDepth);
+            if (shadowTest < 1e-3f) continue;
+            const F3 r = brdf(radiance, fast_normalize(Lv), N, V, alb, roughness, metallic, F0);
+            Lo = Lo + r * shadowTest;
+        } else {
+            Lo = Lo + brdf(radiance, Lv, N, V, alb, roughness, metallic, F0);  // L not normalised (pbr.frag:158)
+        }
+    }
+
+    // ---- directional light with cascaded shadow maps (pbr.frag:163-183, basic.vert:45-48)
+    if (fr.lights_set) {
+        const int ncasc = (int)fr.n_cascades, res = (int)fr.dir_res;
+        int split = 0;
+        float ls0 = 0.0f, ls1 = 0.0f, ls2 = 0.0f;
+        for (; split < ncasc; split++) {
+            const F4 lsp = xform_point(fr.csm_viewproj[split], P.x, P.y, P.z);
+            ls0 = lsp.x * 0.5f + 0.5f; ls1 = lsp.y * 0.5f + 0.5f; ls2 = lsp.z;
+            if (lsp.w != 1.0f) { ls0 /= lsp.w; ls1 /= lsp.w; ls2 /= lsp.w; }
+            if (fminf(ls0, ls1) > 1e-2f && fmaxf(ls0, ls1) < 1.0f - 1e-2f) break;
+        }
+        const int layer = min(split, ncasc - 1);
+        const float shadowTest = shadow_pcf(fr.dir_shadow + (size_t)layer * res * res, res, ls0, ls1, ls2);
+        if (shadowTest > 1e-3f) {
+            const F3 r = brdf(f3(fr.dir_I[0], fr.dir_I[1], fr.dir_I[2]), f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2]), N, V, alb, roughness, metallic, F0);
+            Lo = Lo + r * shadowTest;
+        }
+    }
+
+    // ---- image-based lighting (pbr.frag:186-200)
+    if (fr.prefiltered.res && fr.irradiance.res && fr.lut_w) {
+        const float NdotV = fmaxf(dot3(N, V), 1e-3f);
+        const float lod = fminf(roughness * (float)fr.prefiltered.levels, (float)(fr.prefiltered.levels - 1u));
+        const float fl = floorf(lod), ff = lod - fl;
+        const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, fr.prefiltered.levels - 1u);
+        float s0[3], s1[3], irr[3], lut[2];
+        cube_sample(fr.prefiltered, l0, Rv.x, Rv.y, Rv.z, s0);
+        cube_sample(fr.prefiltered, l1, Rv.x, Rv.y, Rv.z, s1);
+        {
+            const int w = (int)fr.lut_w, h = (int)fr.lut_h;
+            const float lu = NdotV * (float)w - 0.5f, lv = roughness * (float)h - 0.5f;
+            const float fu = floorf(lu), fv = floorf(lv);
+            const float a = lu - fu, b = lv - fv;
+            const int i0 = wrap_index((int)fu, w, 0u), i1 = wrap_index((int)fu + 1, w, 0u);
+            const int j0 = wrap_index((int)fv, h, 0u), j1 = wrap_index((int)fv + 1, h, 0u);
+            const uint32_t* lp = (const uint32_t*)fr.lut;
+            const uint32_t q00 = lp[j0 * w + i0], q10 = lp[j0 * w + i1], q01 = lp[j1 * w + i0], q11 = lp[j1 * w + i1];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float t00 = fr.unorm_decode[(q00 >> (8 * k)) & 255u], t10 = fr.unorm_decode[(q10 >> (8 * k)) & 255u];
+                const float t01 = fr.unorm_decode[(q01 >> (8 * k)) & 255u], t11 = fr.unorm_decode[(q11 >> (8 * k)) & 255u];
+                const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
+                lut[k] = (1.0f - b) * top + b * bot;
+            }
+        }
+        cube_sample(fr.irradiance, 0, N.x, N.y, N.z, irr);
+        const float x = 1.0f - clampf(NdotV, 0.0f, 1.0f);
+        const float x2 = x * x, x5 = x2 * x2 * x;
+        const float F[3] = {F0.x + (1.0f - F0.x) * x5, F0.y + (1.0f - F0.y) * x5, F0.z + (1.0f - F0.z) * x5};
+        float add[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float spec = (1.0f - ff) * s0[k] + ff * s1[k];
+            const float kD = (1.0f - F[k]) * om;
+            add[k] = (kD * irr[k] * albedo[k] + spec * (F[k] * lut[0] + lut[1])) * ao;
+        }
+        Lo = Lo + f3(add[0], add[1], add[2]);
+    }
+    out[0] = fminf(Lo.x + emissive[0], 10.0f);
+    out[1] = fminf(Lo.y + emissive[1], 10.0f);
+    out[2] = fminf(Lo.z + emissive[2], 10.0f);
+    out[3] = mt.alpha_mode == 1 ? 1.0f : albedo[3];
+}
+
+RDR_DEV uint32_t find_draw_by_tri(const uint32_t* __restrict__ first_tri, uint32_t n, uint32_t id) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (first_tri[mid] <= id) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Opaque draws + skybox. S == 1: writes hdr. S == 4: writes the four sample
+// colours when `samples_out` is given (a blended pass follows), else resolves
+// straight into hdr.
+template <int S>
+__global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__ frp, const DDraw* __restrict__ draws,
+                                                      const uint32_t* __restrict__ first_tri, uint32_t n_draws,
+                                                      const float* __restrict__ depth, const uint32_t* __restrict__ vis,
+                                                      uint2* __restrict__ hdr, uint2* __restrict__ samples_out) {
+    const DFrame& fr = *frp;
+    const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
+    const int tx = (int)(blockIdx.x % tiles_x), ty = (int)(blockIdx.x / tiles_x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= (int)fr.W || py >= (int)fr.H) return;
+    const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
+    uint32_t ids[S];
+    float cols[S][4];
+    int n_unique = 0;
+    bool have_sky = false;
+    float sky[4];
+    float sc[S][4];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const uint32_t id = vis[s * plane_px + o];
+        const float zd = depth[s * plane_px + o];
+        if (id == 0xFFFFFFFFu || zd >= 1.0f) {
+            if (!have_sky) { shade_sky(fr, px, py, sky); have_sky = true; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) sc[s][k] = sky[k];
+        } else {
+            int u = 0;
+            for (; u < n_unique; u++) if (ids[u] == id) break;
+            if (u == n_unique) {
+                const uint32_t di = find_draw_by_tri(first_tri, n_draws, id);
+                shade_fragment(fr, draws[di], id - first_tri[di], px, py, cols[u]);
+                ids[u] = id;
+                n_unique++;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) sc[s][k] = cols[u][k];
+        }
+    }
+    if (S == 1) {
+        hdr[o] = pack_half4(sc[0][0], sc[0][1], sc[0][2], sc[0][3]);
+    } else if (samples_out) {
+#pragma unroll
+        for (int s = 0; s < S; s++) samples_out[s * plane_px + o] = pack_half4(sc[s][0], sc[s][1], sc[s][2], sc[s][3]);
+    } else {
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sum[k] += quantize_half(sc[s][k]);
+        hdr[o] = pack_half4(sum[0] * (1.0f / S), sum[1] * (1.0f / S), sum[2] * (1.0f / S), sum[3] * (1.0f / S));
+    }
+}
+
+// Multisample resolve of the four sample colours (after the blended pass).
+__global__ void __launch_bounds__(256) k_resolve4(const uint2* __restrict__ samples, uint2* __restrict__ hdr, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        float c[4];
+        unpack_half4(samples[(size_t)s * n + i], c[0], c[1], c[2], c[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) sum[k] += c[k];
+    }
+    hdr[i] = pack_half4(sum[0] * 0.25f, sum[1] * 0.25f, sum[2] * 0.25f, sum[3] * 0.25f);
+}
+
+#define BLEND_CHUNK 64
+
+// Blended (MASK + BLEND) draws, back to front: same tile walk as k_raster,
+// but every fragment that passes the depth test is shaded at once and blended
+// into the colour target, in list order (VulkanRenderer.cpp:862-866, 1059-1062).
+template <int S>
+__global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__ frp, const DView* __restrict__ views,
+                                                      const DDraw* __restrict__ draws, const uint32_t* __restrict__ first_tri,
+                                                      uint32_t n_draws, const DTriRec* __restrict__ recs,
+                                                      const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
+                                                      const uint32_t* __restrict__ tile_end, uint2* __restrict__ color) {
+    __shared__ uint32_t lds_rec[BLEND_CHUNK * 32];
+    __shared__ uint32_t lds_ids[BLEND_CHUNK];
+    const DFrame& fr = *frp;
+    const DView vw = views[0];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t begin = tile_start[tile], end = tile_end[tile];
+    if (begin >= end) return;
+    const int tx = (int)(tile % vw.tiles_x), ty = (int)(tile / vw.tiles_x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qx0 = tx * RDR_TILE + (wave & 1) * 8, qy0 = ty * RDR_TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool in_view = px < (int)vw.w && py < (int)vw.h;
+    const size_t plane_px = (size_t)vw.w * vw.h, o = (size_t)py * vw.w + px;
+    float z[S];
+    float col[S][4];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        z[s] = in_view ? vw.depth[s * plane_px + o] : 0.0f;
+        if (in_view) unpack_half4(color[s * plane_px + o], col[s][0], col[s][1], col[s][2], col[s][3]);
+        else col[s][0] = col[s][1] = col[s][2] = col[s][3] = 0.0f;
+    }
+    const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
+    for (uint32_t base = begin; base < end; base += BLEND_CHUNK) {
+        const uint32_t cnt = min((uint32_t)BLEND_CHUNK, end - base);
+        __syncthreads();
+        if (threadIdx.x < cnt) lds_ids[threadIdx.x] = sorted_vals[base + threadIdx.x];
+        __syncthreads();
+        for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += 256u) lds_rec[dw] = ((const uint32_t*)(recs + lds_ids[dw >> 5]))[dw & 31u];
+        __syncthreads();
+        bool hit = false;
+        if ((uint32_t)lane < cnt) {
+            const DTriRec* r = (const DTriRec*)(lds_rec + lane * 32);
+            hit = r->px0 <= qx0 + 7 && r->px1 >= qx0 && r->py0 <= qy0 + 7 && r->py1 >= qy0;
+        }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int ri = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const DTriRec* r = (const DTriRec*)(lds_rec + ri * 32);
+            const int n = (int)(r->n_view & 255u);
+            const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
+            uint32_t pass = 0;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const int Px = 256 * px + (S == 1 ? 128 : sxo[s]), Py = 256 * py + (S == 1 ? 128 : syo[s]);
+                bool inside = in_view;
+                for (int i = 0; i < n; i++) {
+                    const int j = (i + 1 == n) ? 0 : i + 1;
+                    const int Xi = r->X[i], Yi = r->Y[i];
+                    const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                    const long long E = (long long)dX * (long long)(Py - Yi) - (long long)dY * (long long)(Px - Xi);
+                    const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+                    inside = inside && (E >= bias);
+                }
+                if (inside) {
+                    float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
+                    zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
+                    if (zz < z[s]) { z[s] = zz; pass |= 1u << s; }
+                }
+            }
+            if (pass) {
+                const uint32_t rid = r->id;
+                const uint32_t di = find_draw_by_tri(first_tri, n_draws, rid);
+                float src[4];
+                shade_fragment(fr, draws[di], rid - first_tri[di], px, py, src);
+                const float a = src[3];
+#pragma unroll
+                for (int s = 0; s < S; s++)
+                    if (pass & (1u << s)) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) col[s][k] = quantize_half(src[k] * a + col[s][k] * (1.0f - a));
+                        col[s][3] = quantize_half(a);
+                    }
+            }
+        }
+    }
+    if (!in_view) return;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        vw.depth[s * plane_px + o] = z[s];
+        color[s * plane_px + o] = pack_half4(col[s][0], col[s][1], col[s][2], col[s][3]);
+    }
+}
+
+}  // namespace
+
+void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws,
+                         const float* depth, const uint32_t* vis, void* hdr, void* samples_out, uint32_t W, uint32_t H) {
+    const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
+    if (samples == 1)
+        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(tiles), dim3(256), 0, s, fr, draws, first_tri, n_draws, depth, vis, (uint2*)hdr, (uint2*)samples_out);
+    else
+        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(tiles), dim3(256), 0, s, fr, draws, first_tri, n_draws, depth, vis, (uint2*)hdr, (uint2*)samples_out);
+}
+void launch_resolve4(hipStream_t s, const void* samples, void* hdr, uint32_t n) {
+    hipLaunchKernelGGL(k_resolve4, dim3((n + 255) / 256), dim3(256), 0, s, (const uint2*)samples, (uint2*)hdr, n);
+}
+void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* views, const DDraw* draws, const uint32_t* first_tri,
+                         uint32_t n_draws, const DTriRec* recs, const uint32_t* sorted_vals, const uint32_t* tile_start,
+                         const uint32_t* tile_end, uint32_t n_tiles, void* color) {
+    if (!n_tiles) return;
+    if (samples == 1)
+        hipLaunchKernelGGL(k_raster_blend<1>, dim3(n_tiles), dim3(256), 0, s, fr, views, draws, first_tri, n_draws, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
+    else
+        hipLaunchKernelGGL(k_raster_blend<4>, dim3(n_tiles), dim3(256), 0, s, fr, views, draws, first_tri, n_draws, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
+}

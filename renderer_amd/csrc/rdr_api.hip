@@ -1,0 +1,1222 @@
+// C ABI of include/rdr.h on HIP: resource management, the host side of
+// renderLoop (matrices, culling, draw ordering, shadow-view set-up, exposure)
+// and the launch sequence of one frame.
+//
+// Reference for the host logic: Renderer/VulkanRenderer.cpp:929-1111
+// (shouldCullMesh, drawMeshes, renderLoop), Renderer/VulkanRendererShadow.cpp:
+// 152-175 (cascade splits), :255-389 (point shadow maps), :391-456 (cascades).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rdr.h"
+#include "kernels.h"
+#include "rdr_host_math.h"
+
+using namespace rdr;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr) {
+        if (bytes <= cap) return hipSuccess;
+        size_t want = std::max(bytes, cap + cap / 2);
+        want = (want + 255) & ~(size_t)255;
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) return e;
+        if (p) {
+            if (keep) { e = hipMemcpyAsync(q, p, cap, hipMemcpyDeviceToDevice, s); if (e == hipSuccess) e = hipStreamSynchronize(s); }
+            (void)hipFree(p);
+            if (e != hipSuccess) { (void)hipFree(q); p = nullptr; cap = 0; return e; }
+        }
+        p = q; cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = std::max(bytes, (size_t)4096) * 2;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct HostImage {
+    DevBuf pixels;
+    uint32_t w = 0, h = 0, levels = 0;
+    bool srgb = false;
+    uint32_t level_offset[RDR_MAX_TEX_LEVELS] = {0};
+};
+struct HostTexture { uint32_t image; rdr_sampler sampler; };
+struct HostPrim {
+    uint32_t first_vertex, first_index, tri_count, n_vertices;
+    vec3 bb_min, bb_max, barycenter;
+    rdr_material mat;
+    uint32_t mesh;
+};
+struct HostMesh { mat4 model; bool is_static; };
+struct HostLight { vec3 point, intensity; uint32_t flags; uint16_t slot; };
+
+struct Batch {
+    std::vector<DView> views;
+    std::vector<DDraw> draws;
+};
+
+}  // namespace
+
+struct rdr_ctx {
+    rdr_settings settings;
+    uint32_t W = 0, H = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene, host side
+    std::vector<std::vector<uint8_t>> buffers;
+    std::vector<HostImage> images;
+    std::vector<HostTexture> textures;
+    std::vector<HostPrim> prims;
+    std::vector<HostMesh> meshes;
+    std::vector<float> h_pos;          // float4 per vertex
+    std::vector<DVertexAttr> h_attr;
+    std::vector<uint32_t> h_idx;
+    bool geometry_dirty = true, textures_dirty = true;
+    Camera camera;
+    std::vector<HostLight> lights;
+    rdr_directional_light dir_light;
+    bool lights_set = false;
+    std::vector<float> cascade_depths, cascade_camera_depths;
+    mat4 csm_viewproj[4];
+
+    // scene, device side
+    DevBuf d_pos, d_attr, d_idx, d_prims, d_textures, d_lights, d_tables, d_trig;
+    DevBuf d_env, d_irradiance, d_prefiltered, d_lut;
+    DCube env{}, irradiance{}, prefiltered{};
+    uint32_t lut_w = 0, lut_h = 0;
+
+    // frame targets
+    DevBuf d_depth, d_vis, d_samples, d_hdr, d_bloom, d_out, d_loglum, d_lum, d_dir_shadow, d_point_shadow, d_point_static;
+    uint32_t bloom_offset[6], bloom_w[6], bloom_h[6];
+    bool have_frame = false, have_post = false;
+
+    // raster scratch
+    DevBuf d_views, d_draws, d_draw_first, d_first_tri, d_recs, d_pair_count, d_scan, d_hist, d_tile_start, d_tile_end, d_counters, d_frame;
+    DevBuf d_keys[2], d_vals[2];
+    PinBuf h_stage, h_read;
+    std::vector<DDraw> main_draws;  // opaque draws of the last frame (kept for read-backs)
+
+    float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
+    rdr_frame_stats stats{};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int fail(rdr_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+int hip_fail(rdr_ctx* c, const char* what, hipError_t e) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    return fail(c, RDR_ERR_DEVICE, buf);
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(c, #expr, e_); } while (0)
+#define RDR_TRY(expr) do { int r_ = (expr); if (r_ != RDR_OK) return r_; } while (0)
+
+double srgb_eotf(double v) { return v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); }
+
+// Renderer/Camera.cpp:245-280, planes pointing into the frustum
+void frustum_planes(const mat4& M, vec4 pl[6]) {
+    pl[0] = {M.at(0, 3) + M.at(0, 0), M.at(1, 3) + M.at(1, 0), M.at(2, 3) + M.at(2, 0), M.at(3, 3) + M.at(3, 0)};
+    pl[1] = {M.at(0, 3) - M.at(0, 0), M.at(1, 3) - M.at(1, 0), M.at(2, 3) - M.at(2, 0), M.at(3, 3) - M.at(3, 0)};
+    pl[2] = {M.at(0, 3) + M.at(0, 1), M.at(1, 3) + M.at(1, 1), M.at(2, 3) + M.at(2, 1), M.at(3, 3) + M.at(3, 1)};
+    pl[3] = {M.at(0, 3) - M.at(0, 1), M.at(1, 3) - M.at(1, 1), M.at(2, 3) - M.at(2, 1), M.at(3, 3) - M.at(3, 1)};
+    pl[4] = {M.at(0, 3) - M.at(0, 2), M.at(1, 3) - M.at(1, 2), M.at(2, 3) - M.at(2, 2), M.at(3, 3) - M.at(3, 2)};
+    pl[5] = {M.at(0, 2), M.at(1, 2), M.at(2, 2), M.at(3, 2)};
+}
+// Renderer/VulkanRenderer.cpp:929-943
+bool should_cull(const HostPrim& p, const mat4& model, const mat4& viewproj) {
+    vec4 pl[6];
+    frustum_planes(mat_mul(viewproj, model), pl);
+    for (int i = 0; i < 6; i++) {
+        vec3 n = p.bb_min;
+        if (pl[i].x >= 0.0f) n.x = p.bb_max.x;
+        if (pl[i].y >= 0.0f) n.y = p.bb_max.y;
+        if (pl[i].z >= 0.0f) n.z = p.bb_max.z;
+        if (dot(n, make3(pl[i].x, pl[i].y, pl[i].z)) + pl[i].w < 0.0f) return true;
+    }
+    return false;
+}
+
+enum SortMode { SORT_NONE, SORT_FRONT_TO_BACK, SORT_BACK_TO_FRONT };
+
+// drawMeshes (VulkanRenderer.cpp:945-999): sort by distance(barycenter, eye), frustum-cull, one draw per primitive.
+void append_draws(const rdr_ctx* c, const std::vector<uint32_t>& prim_list, const mat4& viewproj, vec3 eye, SortMode mode, uint32_t view,
+                  std::vector<DDraw>& out) {
+    std::vector<uint32_t> order(prim_list);
+    if (mode != SORT_NONE) {
+        std::vector<float> key(c->prims.size());
+        for (uint32_t p : order) key[p] = distance(c->prims[p].barycenter, eye);
+        if (mode == SORT_FRONT_TO_BACK) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        else std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] > key[b]; });
+    }
+    uint32_t first_tri = 0;
+    for (uint32_t p : order) {
+        const HostPrim& pr = c->prims[p];
+        const mat4& model = c->meshes[pr.mesh].model;
+        if (should_cull(pr, model, viewproj)) continue;
+        DDraw d;
+        const mat4 mvp = mat_mul(viewproj, model);
+        memcpy(d.mvp, mvp.m, 64);
+        memcpy(d.model, model.m, 64);
+        d.view = view; d.prim = p; d.first_instance = 0; d.first_tri_id = first_tri;
+        first_tri += pr.tri_count;
+        out.push_back(d);
+    }
+}
+
+// VulkanRendererShadow.cpp:152-175
+void compute_cascade_splits(rdr_ctx* c) {
+    c->cascade_depths.clear(); c->cascade_camera_depths.clear();
+    c->cascade_depths.push_back(c->camera.near_plane);
+    c->cascade_camera_depths.push_back(0.0f);
+    const float n = c->camera.near_plane, f = c->camera.far_plane;
+    const int levels = (int)c->settings.directional_shadow_cascade_levels;
+    for (int i = 1; i < levels; i++) {
+        const float N = (float)levels;
+        const float Cuni = n + (f - n) * i / N;
+        const float Clog = n * powf(f / n, i / N);
+        const float lambda = 0.9f;
+        const float d = lambda * Clog + (1 - lambda) * Cuni;
+        c->cascade_depths.push_back(d);
+        c->cascade_camera_depths.push_back((f - f * n / d) / (f - n));
+    }
+}
+
+size_t value_size(uint32_t t) {
+    switch (t) {
+        case RDR_INT8: case RDR_UINT8: return 1;
+        case RDR_INT16: case RDR_UINT16: case RDR_HALF: return 2;
+        case RDR_INT32: case RDR_UINT32: case RDR_FLOAT: return 4;
+        default: return 8;
+    }
+}
+float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t bits;
+    if (e == 0) { float v = (float)m * 5.9604644775390625e-08f; return sign ? -v : v; }
+    if (e == 31) bits = sign | 0x7F800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+float component_as_float(const uint8_t* p, uint32_t value_type, bool normalized) {
+    switch (value_type) {
+        case RDR_FLOAT: { float f; memcpy(&f, p, 4); return f; }
+        case RDR_UINT8: return normalized ? (float)p[0] / 255.0f : (float)p[0];
+        case RDR_UINT16: { uint16_t v; memcpy(&v, p, 2); return normalized ? (float)v / 65535.0f : (float)v; }
+        case RDR_HALF: { uint16_t v; memcpy(&v, p, 2); return half_bits_to_float(v); }
+        default: return 0.0f;
+    }
+}
+
+int upload_scene(rdr_ctx* c) {
+    if (c->geometry_dirty) {
+        HIP_TRY(c->d_pos.ensure(std::max<size_t>(c->h_pos.size() * 4, 16)));
+        HIP_TRY(c->d_attr.ensure(std::max<size_t>(c->h_attr.size() * sizeof(DVertexAttr), 48)));
+        HIP_TRY(c->d_idx.ensure(std::max<size_t>(c->h_idx.size() * 4, 16)));
+        if (!c->h_pos.empty()) {
+            HIP_TRY(hipMemcpy(c->d_pos.p, c->h_pos.data(), c->h_pos.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_attr.p, c->h_attr.data(), c->h_attr.size() * sizeof(DVertexAttr), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_idx.p, c->h_idx.data(), c->h_idx.size() * 4, hipMemcpyHostToDevice));
+        }
+        std::vector<DPrim> dp(std::max<size_t>(c->prims.size(), 1));
+        for (size_t i = 0; i < c->prims.size(); i++) {
+            const HostPrim& p = c->prims[i];
+            DPrim& d = dp[i];
+            memset(&d, 0, sizeof d);
+            d.first_vertex = p.first_vertex; d.first_index = p.first_index; d.tri_count = p.tri_count;
+            memcpy(d.mat.base_color, p.mat.base_color_factor, 16);
+            memcpy(d.mat.emissive, p.mat.emissive_factor, 16);
+            d.mat.metallic = p.mat.metallic_factor; d.mat.roughness = p.mat.roughness_factor; d.mat.ao = p.mat.ao_factor;
+            d.mat.alpha_cutoff = p.mat.alpha_cutoff; d.mat.alpha_mode = p.mat.alpha_mode;
+            d.mat.tex[0] = p.mat.albedo_texture; d.mat.tex[1] = p.mat.normal_texture; d.mat.tex[2] = p.mat.metal_roughness_texture;
+            d.mat.tex[3] = p.mat.ao_texture; d.mat.tex[4] = p.mat.emissive_texture;
+        }
+        HIP_TRY(c->d_prims.ensure(dp.size() * sizeof(DPrim)));
+        HIP_TRY(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+        c->geometry_dirty = false;
+    }
+    if (c->textures_dirty) {
+        std::vector<DTexture> dt(c->textures.size());
+        for (size_t i = 0; i < c->textures.size(); i++) {
+            const HostTexture& t = c->textures[i];
+            const HostImage& img = c->images[t.image];
+            DTexture& d = dt[i];
+            memset(&d, 0, sizeof d);
+            d.base = (const uint8_t*)img.pixels.p;
+            d.w = img.w; d.h = img.h; d.levels = img.levels;
+            d.flags = (img.srgb ? 1u : 0u) | (t.sampler.wrap_u << 4) | (t.sampler.wrap_v << 8);
+            memcpy(d.level_offset, img.level_offset, sizeof d.level_offset);
+        }
+        HIP_TRY(c->d_textures.ensure(dt.size() * sizeof(DTexture)));
+        HIP_TRY(hipMemcpy(c->d_textures.p, dt.data(), dt.size() * sizeof(DTexture), hipMemcpyHostToDevice));
+        c->textures_dirty = false;
+    }
+    return RDR_OK;
+}
+
+int create_image(rdr_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h, bool srgb, uint32_t max_mips, uint32_t* out_id) {
+    HostImage img;
+    img.w = w; img.h = h; img.srgb = srgb;
+    uint32_t levels = 1;
+    const uint32_t m = std::max(w, h);
+    if (m > 1) levels = (uint32_t)floor(log2((double)m)) + 1;  // VulkanRenderer.cpp:311-315
+    levels = std::max(1u, std::min(std::min(levels, max_mips), (uint32_t)RDR_MAX_TEX_LEVELS));
+    img.levels = levels;
+    size_t texels = 0;
+    for (uint32_t l = 0; l < levels; l++) {
+        img.level_offset[l] = (uint32_t)texels;
+        texels += (size_t)std::max(1u, w >> l) * std::max(1u, h >> l);
+    }
+    HIP_TRY(img.pixels.ensure(texels * 4));
+    HIP_TRY(hipMemcpyAsync(img.pixels.p, rgba, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream));
+    const float* tables = c->d_tables.as<float>();
+    for (uint32_t l = 1; l < levels; l++) {
+        uint32_t* base = img.pixels.as<uint32_t>();
+        launch_mip_blit(c->stream, base + img.level_offset[l - 1], (int)std::max(1u, w >> (l - 1)), (int)std::max(1u, h >> (l - 1)),
+                        base + img.level_offset[l], (int)std::max(1u, w >> l), (int)std::max(1u, h >> l), srgb ? 1 : 0, tables, tables + 256,
+                        tables + 512);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    c->images.push_back(img);
+    *out_id = (uint32_t)c->images.size() - 1;
+    return RDR_OK;
+}
+
+// Runs set-up -> bin -> sort for one batch of views. On return the sorted
+// triangle lists of every tile are in d_vals[*cur] / d_tile_start / d_tile_end.
+int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
+    uint32_t n_tiles = 0;
+    for (DView& v : b.views) {
+        v.tiles_x = (v.w + RDR_TILE - 1) / RDR_TILE; v.tiles_y = (v.h + RDR_TILE - 1) / RDR_TILE;
+        v.tile_base = n_tiles;
+        n_tiles += v.tiles_x * v.tiles_y;
+    }
+    const uint32_t n_draws = (uint32_t)b.draws.size();
+    std::vector<uint32_t> draw_first(n_draws + 1, 0), first_tri(n_draws + 1, 0);
+    uint64_t inst64 = 0;
+    for (uint32_t i = 0; i < n_draws; i++) {
+        b.draws[i].first_instance = (uint32_t)inst64;
+        draw_first[i] = (uint32_t)inst64;
+        first_tri[i] = b.draws[i].first_tri_id;
+        inst64 += c->prims[b.draws[i].prim].tri_count;
+    }
+    if (inst64 >= 0xFFFFFFF0ull) return fail(c, RDR_ERR_CAPACITY, "more than 2^32 triangle instances in one batch");
+    const uint32_t n_inst = (uint32_t)inst64;
+    draw_first[n_draws] = n_inst;
+    // stage the tables in pinned memory and upload
+    const size_t sz_views = b.views.size() * sizeof(DView), sz_draws = std::max<size_t>(n_draws, 1) * sizeof(DDraw), sz_first = (n_draws + 1) * 4;
+    HIP_TRY(c->h_stage.ensure(sz_views + sz_draws + 2 * sz_first + 64));
+    uint8_t* st = c->h_stage.as<uint8_t>();
+    memcpy(st, b.views.data(), sz_views);
+    if (n_draws) memcpy(st + sz_views, b.draws.data(), n_draws * sizeof(DDraw));
+    memcpy(st + sz_views + sz_draws, draw_first.data(), sz_first);
+    memcpy(st + sz_views + sz_draws + sz_first, first_tri.data(), sz_first);
+    HIP_TRY(c->d_views.ensure(sz_views));
+    HIP_TRY(c->d_draws.ensure(sz_draws));
+    HIP_TRY(c->d_draw_first.ensure(sz_first));
+    HIP_TRY(c->d_first_tri.ensure(sz_first));
+    HIP_TRY(hipMemcpyAsync(c->d_views.p, st, sz_views, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_draws.p, st + sz_views, sz_draws, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_draw_first.p, st + sz_views + sz_draws, sz_first, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_first_tri.p, st + sz_views + sz_draws + sz_first, sz_first, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c->d_recs.ensure(std::max<size_t>(n_inst, 1) * sizeof(DTriRec)));
+    HIP_TRY(c->d_pair_count.ensure(std::max<size_t>(n_inst, 1) * 4));
+    HIP_TRY(c->d_tile_start.ensure(std::max<size_t>(n_tiles, 1) * 4));
+    HIP_TRY(c->d_tile_end.ensure(std::max<size_t>(n_tiles, 1) * 4));
+    HIP_TRY(c->d_scan.ensure((scan_scratch_words(n_inst) + 16) * 4));
+    uint32_t* counters = c->d_counters.as<uint32_t>();  // [0] pair total, [1] triangles binned (frame), [2] scratch total, [3] valid pairs
+    launch_setup(c->stream, c->d_views.as<DView>(), c->d_draws.as<DDraw>(), c->d_draw_first.as<uint32_t>(), n_draws, n_inst,
+                 c->d_prims.as<DPrim>(), c->d_pos.p, c->d_idx.as<uint32_t>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(),
+                 counters + 1);
+    launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
+    HIP_TRY(c->h_read.ensure(64));
+    HIP_TRY(hipMemcpyAsync(c->h_read.p, counters, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n_pairs = c->h_read.as<uint32_t>()[0];
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(c->d_keys[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
+        HIP_TRY(c->d_vals[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
+    }
+    HIP_TRY(c->d_hist.ensure((sort_hist_words(n_pairs) + 16) * 4));
+    HIP_TRY(c->d_scan.ensure((scan_scratch_words((uint32_t)sort_hist_words(n_pairs)) + scan_scratch_words(n_inst) + 16) * 4));
+    launch_emit(c->stream, c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(), n_inst, n_pairs,
+                c->d_keys[0].as<uint32_t>(), c->d_vals[0].as<uint32_t>());
+    uint32_t key_bits = 1;
+    while ((1ull << key_bits) <= n_tiles) key_bits++;
+    uint32_t* keys[2] = {c->d_keys[0].as<uint32_t>(), c->d_keys[1].as<uint32_t>()};
+    uint32_t* vals[2] = {c->d_vals[0].as<uint32_t>(), c->d_vals[1].as<uint32_t>()};
+    const int cur = launch_radix_sort(c->stream, keys, vals, n_pairs, key_bits, c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(), counters + 2);
+    launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, counters + 3);
+    c->stats.triangle_instances += n_inst;
+    c->stats.tile_pairs += n_pairs;
+    c->stats.views += (uint32_t)b.views.size();
+    *out_tiles = n_tiles;
+    *out_cur = cur;
+    return RDR_OK;
+}
+
+int raster_batch(rdr_ctx* c, Batch& b) {
+    if (b.views.empty()) return RDR_OK;
+    uint32_t n_tiles = 0;
+    int cur = 0;
+    RDR_TRY(bin_batch(c, b, &n_tiles, &cur));
+    bool s1 = false, s4 = false;
+    for (const DView& v : b.views) (v.samples == 4 ? s4 : s1) = true;
+    launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                  c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, s1, s4);
+    HIP_TRY(hipGetLastError());
+    return RDR_OK;
+}
+
+DView make_view(float* depth, uint32_t* vis, uint32_t w, uint32_t h, uint32_t samples, uint32_t cull, uint32_t load) {
+    DView v;
+    memset(&v, 0, sizeof v);
+    v.depth = depth; v.vis = vis; v.w = w; v.h = h; v.samples = samples; v.cull = cull; v.load = load;
+    return v;
+}
+
+// recordPointShadowMapsCommands (VulkanRendererShadow.cpp:255-389)
+int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
+    const uint32_t count = c->settings.point_shadow_map_count;
+    std::vector<uint32_t> casters;
+    for (uint32_t i = 0; i < c->lights.size(); i++)
+        if (c->lights[i].flags & RDR_POINT_LIGHT_CAST_SHADOWS) casters.push_back(i);
+    if (casters.empty() || count == 0) return RDR_OK;
+    const uint32_t res = c->settings.point_shadow_map_resolution;
+    const size_t face_px = (size_t)res * res, total_bytes = face_px * 6 * count * 4;
+    if (c->d_point_shadow.cap < total_bytes) {
+        HIP_TRY(c->d_point_shadow.ensure(total_bytes));
+        HIP_TRY(c->d_point_static.ensure(total_bytes));
+    }
+    static const vec3 dirs[6] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    static const vec3 ups[6] = {{0, 1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};
+    Camera face[6];
+    for (int j = 0; j < 6; j++) {
+        face[j].type = 0;
+        face[j].euler = quat_euler(quat_look_at(dirs[j], ups[j]));
+        face[j].near_plane = 0.1f; face[j].far_plane = 100.0f;
+        face[j].fov_or_height = 90.0f * 0.01745329251994329576923690768489f;
+        face[j].aspect = 1.0f;
+        face[j].crop = mat_scale(make3(-1.0f, 1.0f, 1.0f));
+    }
+    std::vector<float> key(c->lights.size());
+    for (uint32_t i : casters) key[i] = distance(c->lights[i].point, camera_pos);
+    std::stable_sort(casters.begin(), casters.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    std::vector<uint32_t> slotted;
+    uint16_t slot = 0;
+    for (uint32_t i : casters) {
+        HostLight& l = c->lights[i];
+        if (slot < count) {
+            slotted.push_back(i);
+            if (l.slot != slot) l.flags &= ~RDR_POINT_LIGHT_STATIC_SHADOW_MAP_RENDERED;
+            l.slot = slot;
+            l.flags |= RDR_POINT_LIGHT_HAS_SHADOW_MAP;
+            slot++;
+        } else {
+            l.slot = 0xFFFF;
+            l.flags &= ~(RDR_POINT_LIGHT_STATIC_SHADOW_MAP_RENDERED | RDR_POINT_LIGHT_HAS_SHADOW_MAP);
+        }
+    }
+    std::vector<uint32_t> static_prims, dynamic_prims;
+    for (uint32_t p = 0; p < c->prims.size(); p++) (c->meshes[c->prims[p].mesh].is_static ? static_prims : dynamic_prims).push_back(p);
+    // static maps of the lights whose slot is stale, all faces in one batch
+    Batch sb;
+    std::vector<uint32_t> refreshed;
+    for (uint32_t i : slotted) {
+        HostLight& l = c->lights[i];
+        if (l.flags & RDR_POINT_LIGHT_STATIC_SHADOW_MAP_RENDERED) continue;
+        for (int j = 0; j < 6; j++) {
+            face[j].position = l.point;
+            const mat4 vp = face[j].view_proj();
+            float* dst = c->d_point_static.as<float>() + ((size_t)l.slot * 6 + j) * face_px;
+            sb.views.push_back(make_view(dst, nullptr, res, res, 1, 1, 0));
+            append_draws(c, static_prims, vp, l.point, SORT_FRONT_TO_BACK, (uint32_t)sb.views.size() - 1, sb.draws);
+        }
+        l.flags |= RDR_POINT_LIGHT_STATIC_SHADOW_MAP_RENDERED;
+        refreshed.push_back(i);
+    }
+    if (!sb.views.empty()) {
+        RDR_TRY(raster_batch(c, sb));
+        for (uint32_t i : refreshed) {
+            const size_t off = (size_t)c->lights[i].slot * 6 * face_px;
+            HIP_TRY(hipMemcpyAsync(c->d_point_shadow.as<float>() + off, c->d_point_static.as<float>() + off, 6 * face_px * 4,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    // dynamic meshes on top of a copy of the static face
+    for (uint32_t i : slotted) {
+        HostLight& l = c->lights[i];
+        for (int j = 0; j < 6; j++) {
+            face[j].position = l.point;
+            const mat4 vp = face[j].view_proj();
+            const size_t n_before = dynamic_batch.draws.size();
+            append_draws(c, dynamic_prims, vp, l.point, SORT_FRONT_TO_BACK, (uint32_t)dynamic_batch.views.size(), dynamic_batch.draws);
+            if (c->settings.dynamic_shadows_enabled && dynamic_batch.draws.size() > n_before) {
+                const size_t off = ((size_t)l.slot * 6 + j) * face_px;
+                HIP_TRY(hipMemcpyAsync(c->d_point_shadow.as<float>() + off, c->d_point_static.as<float>() + off, face_px * 4,
+                                       hipMemcpyDeviceToDevice, c->stream));
+                dynamic_batch.views.push_back(make_view(c->d_point_shadow.as<float>() + off, nullptr, res, res, 1, 1, 1));
+            } else {
+                dynamic_batch.draws.resize(n_before);
+            }
+        }
+    }
+    return RDR_OK;
+}
+
+// recordDirectionalShadowMapsCommands (VulkanRendererShadow.cpp:391-456)
+int cascade_views(rdr_ctx* c, Batch& b) {
+    const uint32_t levels = c->settings.directional_shadow_cascade_levels, res = c->settings.directional_shadow_map_resolution;
+    const size_t px = (size_t)res * res;
+    HIP_TRY(c->d_dir_shadow.ensure(px * levels * 4));
+    Camera light;  // DirectionalLight::lightViewCamera (DirectionalLight.cpp:3-5)
+    light.type = 1;
+    light.position = make3(c->dir_light.position[0], c->dir_light.position[1], c->dir_light.position[2]);
+    const quat q = {c->dir_light.orientation_wxyz[0], c->dir_light.orientation_wxyz[1], c->dir_light.orientation_wxyz[2], c->dir_light.orientation_wxyz[3]};
+    light.euler = quat_euler(q);
+    light.near_plane = 0.1f; light.far_plane = 200.0f; light.fov_or_height = 10.0f; light.aspect = 1.0f;
+    light.crop = mat_identity();
+    const mat4 light_vp = light.view_proj();
+    std::vector<uint32_t> all(c->prims.size());
+    for (uint32_t p = 0; p < all.size(); p++) all[p] = p;
+    static const float ndc[8][3] = {{-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1}};
+    for (uint32_t i = 0; i < levels; i++) {
+        Camera split = c->camera;  // the reference's Camera copy drops the crop matrix (Camera.cpp:3-41)
+        split.crop = mat_identity();
+        split.near_plane = c->cascade_depths[i];
+        if (i < levels - 1) split.far_plane = c->cascade_depths[i + 1];
+        // Camera::getFrustumVertices (Camera.cpp:218-242) then makeAABBFromVertices in light clip space (:306-329)
+        const mat4 inv = mat_inverse(split.view_proj());
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < 8; k++) {
+            const vec4 vh = mat_mul_vec(inv, vec4{ndc[k][0], ndc[k][1], ndc[k][2], 1.0f});
+            const vec4 h = mat_mul_vec(light_vp, vec4{vh.x / vh.w, vh.y / vh.w, vh.z / vh.w, 1.0f});
+            const float v[3] = {h.x / h.w, h.y / h.w, h.z / h.w};
+            for (int a = 0; a < 3; a++) { if (v[a] < mn[a]) mn[a] = v[a]; if (v[a] > mx[a]) mx[a] = v[a]; }
+        }
+        const float largest = std::max(mx[0] - mn[0], mx[1] - mn[1]);
+        const vec3 offset = make3(-((mx[0] + mn[0]) / 2), -((mx[1] + mn[1]) / 2), -0.0f);
+        Camera split_pov = light;
+        split_pov.crop = mat_mul(mat_scale(make3(1.0f / largest, 1.0f / largest, 1.0f)), mat_translate(offset));
+        const mat4 vp = split_pov.view_proj();
+        c->csm_viewproj[i] = vp;
+        b.views.push_back(make_view(c->d_dir_shadow.as<float>() + (size_t)i * px, nullptr, res, res, 1, 1, 0));
+        append_draws(c, all, vp, split_pov.position, SORT_FRONT_TO_BACK, (uint32_t)b.views.size() - 1, b.draws);
+    }
+    return RDR_OK;
+}
+
+// exposure recurrence (VulkanRenderer.cpp:1075-1082)
+float compute_exposure(rdr_ctx* c, const rdr_frame_params* fp) {
+    if (fp && fp->exposure_mode == 2) return fp->exposure;
+    if (fp && fp->exposure_mode == 1) c->temporal_luminance = fp->temporal_luminance;
+    else {
+        const double dt = fp ? (double)fp->delta_time : 1.0 / 60.0;
+        const float avg = std::min(c->last_avg_log_lum, 10.0f);
+        c->temporal_luminance = (float)(c->temporal_luminance + (exp2f(avg) - c->temporal_luminance) * (1 - exp(-dt)));
+    }
+    float exposure = 1.03f - 2 / (log2f(c->temporal_luminance + 1.0f) + 2);
+    exposure = 0.18f / exposure + c->settings.exposure_bias;
+    return exposure;
+}
+
+float tone_curve(float x) {  // tonemap.comp:26-28
+    const float shoulderStr = 0.22f, linStr = 0.30f, linAngle = 0.10f, toeStr = 0.20f, toeNum = 0.01f, toeDenom = 0.30f;
+    return ((x * (shoulderStr * x + linAngle * linStr) + toeStr * toeNum) / (x * (shoulderStr * x + linStr) + toeStr * toeDenom)) - toeNum / toeDenom;
+}
+
+int ensure_post_targets(rdr_ctx* c) {
+    const size_t n = (size_t)c->W * c->H;
+    HIP_TRY(c->d_hdr.ensure(n * 8));
+    size_t off = 0;
+    for (uint32_t l = 0; l < 6; l++) {
+        c->bloom_w[l] = std::max(1u, c->W >> l); c->bloom_h[l] = std::max(1u, c->H >> l);
+        c->bloom_offset[l] = (uint32_t)off;
+        off += (size_t)c->bloom_w[l] * c->bloom_h[l];
+    }
+    HIP_TRY(c->d_bloom.ensure(off * 4));
+    HIP_TRY(c->d_out.ensure(n * 4));
+    HIP_TRY(c->d_loglum.ensure(n * 4));
+    HIP_TRY(c->d_lum.ensure((256 + 16) * 4));
+    return RDR_OK;
+}
+
+// bloom chain + tonemap + average luminance (VulkanRendererBloom.cpp:62-100, VulkanRenderer.cpp:1084-1109, 1156-1191)
+void enqueue_post(rdr_ctx* c, float exposure) {
+    const uint32_t n = c->W * c->H;
+    uint32_t* bloom = c->d_bloom.as<uint32_t>();
+    (void)hipEventRecord(c->ev[2], c->stream);
+    launch_hdr_to_bloom0(c->stream, c->d_hdr.p, bloom, n);
+    for (uint32_t i = 0; i < 5; i++)
+        launch_bloom_down(c->stream, bloom + c->bloom_offset[i], (int)c->bloom_w[i], (int)c->bloom_h[i], bloom + c->bloom_offset[i + 1],
+                          (int)(c->W >> (i + 1)), (int)(c->H >> (i + 1)), (int)c->bloom_w[i + 1]);
+    for (uint32_t i = 0; i < 5; i++) {
+        const uint32_t dl = 4 - i, sl = 5 - i;
+        launch_bloom_up(c->stream, bloom + c->bloom_offset[sl], (int)c->bloom_w[sl], (int)c->bloom_h[sl], bloom + c->bloom_offset[dl],
+                        (int)(c->W >> dl), (int)(c->H >> dl), (int)c->bloom_w[dl]);
+    }
+    (void)hipEventRecord(c->ev[3], c->stream);
+    launch_tonemap(c->stream, c->d_hdr.p, bloom, c->d_out.as<uint32_t>(), c->d_loglum.as<float>(), n, powf(2.0f, exposure),
+                   1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
+    launch_average_luminance(c->stream, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), c->d_lum.as<float>() + 256);
+    (void)hipEventRecord(c->ev[4], c->stream);
+    c->have_post = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdr_settings_default(rdr_settings* s) {
+    if (!s) return RDR_ERR_INVALID;
+    const rdr_settings d = {0, 1, 512, 8, 2048, 4, 0, 0.0f, 2.2f, 4};
+    *s = d;
+    return RDR_OK;
+}
+
+const char* rdr_backend_name(void) { return "hip:gfx950"; }
+
+int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, int device, rdr_ctx** out) {
+    if (!settings || !out || width == 0 || height == 0 || width > 16384 || height > 16384) return RDR_ERR_INVALID;
+    if ((settings->msaa != 1 && settings->msaa != 4) || settings->directional_shadow_cascade_levels < 1 ||
+        settings->directional_shadow_cascade_levels > RDR_MAX_CASCADES)
+        return RDR_ERR_UNSUPPORTED;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RDR_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RDR_ERR_DEVICE;
+    rdr_ctx* c = new (std::nothrow) rdr_ctx();
+    if (!c) return RDR_ERR_DEVICE;
+    c->settings = *settings; c->W = width; c->H = height; c->device = device;
+    memset(&c->dir_light, 0, sizeof c->dir_light);
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    for (int i = 0; i < 6 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
+    std::vector<float> tables(768);
+    for (int i = 0; i < 256; i++) {
+        tables[i] = (float)srgb_eotf((double)i / 255.0);
+        tables[256 + i] = (float)i / 255.0f;
+        tables[512 + i] = (float)srgb_eotf(((double)i + 0.5) / 255.0);
+    }
+    ok = ok && c->d_tables.ensure(768 * 4) == hipSuccess && hipMemcpy(c->d_tables.p, tables.data(), 768 * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && c->d_counters.ensure(64) == hipSuccess && hipMemset(c->d_counters.p, 0, 64) == hipSuccess;
+    ok = ok && c->d_frame.ensure(sizeof(DFrame)) == hipSuccess;
+    if (!ok) { rdr_destroy(c); return RDR_ERR_DEVICE; }
+    c->camera.type = 0;  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
+    c->camera.position = make3(0, 0, 0); c->camera.euler = make3(0, 0, 0);
+    c->camera.near_plane = 0.1f; c->camera.far_plane = 60.0f;
+    c->camera.fov_or_height = 40.0f * 0.01745329251994329576923690768489f;
+    c->camera.aspect = (float)width / (float)height;
+    c->camera.crop = mat_identity();
+    // default textures: 1x1 white (VulkanRenderer.h:28-32), 1x1 (128,128,255,0) (textures/clear_normal.png)
+    const uint8_t white[4] = {255, 255, 255, 255}, nrm[4] = {128, 128, 255, 0};
+    uint32_t id;
+    const rdr_sampler smp = {RDR_FILTER_LINEAR, RDR_FILTER_LINEAR, RDR_FILTER_LINEAR, RDR_WRAP_REPEAT, RDR_WRAP_REPEAT};
+    if (create_image(c, white, 1, 1, false, 1, &id) != RDR_OK || create_image(c, nrm, 1, 1, false, 1, &id) != RDR_OK) { rdr_destroy(c); return RDR_ERR_DEVICE; }
+    c->textures.push_back(HostTexture{0, smp});
+    c->textures.push_back(HostTexture{1, smp});
+    *out = c;
+    return RDR_OK;
+}
+
+void rdr_destroy(rdr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_pos, &c->d_attr, &c->d_idx, &c->d_prims, &c->d_textures, &c->d_lights, &c->d_tables, &c->d_trig, &c->d_env,
+                      &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
+                      &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_views, &c->d_draws,
+                      &c->d_draw_first, &c->d_first_tri, &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start, &c->d_tile_end,
+                      &c->d_counters, &c->d_frame, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
+    for (DevBuf* b : bufs) b->release();
+    for (HostImage& img : c->images) img.pixels.release();
+    c->h_stage.release(); c->h_read.release();
+    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rdr_last_error(const rdr_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rdr_load_buffer(rdr_ctx* c, const void* ptr, size_t size, uint32_t* out_id) {
+    if (!c || !ptr || !out_id) return fail(c, RDR_ERR_INVALID, "load_buffer: null argument");
+    c->buffers.emplace_back((const uint8_t*)ptr, (const uint8_t*)ptr + size);
+    *out_id = (uint32_t)c->buffers.size() - 1;
+    return RDR_OK;
+}
+
+int rdr_load_image(rdr_ctx* c, const void* ptr, size_t size, uint32_t w, uint32_t h, int format, uint32_t max_mips, uint32_t* out_id) {
+    if (!c || !ptr || !out_id || w == 0 || h == 0) return fail(c, RDR_ERR_INVALID, "load_image: bad argument");
+    int ch; bool srgb;
+    switch (format) {
+        case RDR_FORMAT_R8G8B8_UNORM: ch = 3; srgb = false; break;
+        case RDR_FORMAT_R8G8B8_SRGB: ch = 3; srgb = true; break;
+        case RDR_FORMAT_R8G8B8A8_UNORM: ch = 4; srgb = false; break;
+        case RDR_FORMAT_R8G8B8A8_SRGB: ch = 4; srgb = true; break;
+        default: return fail(c, RDR_ERR_UNSUPPORTED, "load_image: only 8-bit formats are supported");
+    }
+    if (size < (size_t)w * h * ch) return fail(c, RDR_ERR_INVALID, "load_image: size too small");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint8_t* s = (const uint8_t*)ptr;
+    std::vector<uint8_t> rgba;
+    if (ch == 3) {
+        rgba.resize((size_t)w * h * 4);
+        for (size_t i = 0; i < (size_t)w * h; i++) { rgba[i * 4] = s[i * 3]; rgba[i * 4 + 1] = s[i * 3 + 1]; rgba[i * 4 + 2] = s[i * 3 + 2]; rgba[i * 4 + 3] = 255; }
+        s = rgba.data();
+    }
+    return create_image(c, s, w, h, srgb, max_mips, out_id);
+}
+
+int rdr_make_texture(rdr_ctx* c, uint32_t image, const rdr_sampler* s, uint32_t* out_id) {
+    if (!c || !s || !out_id || image >= c->images.size()) return fail(c, RDR_ERR_INVALID, "make_texture: bad argument");
+    if (s->mag_filter != RDR_FILTER_LINEAR || s->min_filter != RDR_FILTER_LINEAR || s->mipmap_filter != RDR_FILTER_LINEAR)
+        return fail(c, RDR_ERR_UNSUPPORTED, "make_texture: only LINEAR filters are supported");
+    if (s->wrap_u > RDR_WRAP_CLAMP || s->wrap_v > RDR_WRAP_CLAMP) return fail(c, RDR_ERR_INVALID, "make_texture: bad wrap mode");
+    c->textures.push_back(HostTexture{image, *s});
+    c->textures_dirty = true;
+    *out_id = (uint32_t)c->textures.size() - 1;
+    return RDR_OK;
+}
+
+int rdr_add_mesh(rdr_ctx* c, const rdr_primitive_desc* descs, uint32_t count, const float model[16], int is_static, uint32_t* out_mesh_id) {
+    if (!c || !descs || !model || count == 0) return fail(c, RDR_ERR_INVALID, "add_mesh: bad argument");
+    HostMesh mesh;
+    memcpy(mesh.model.m, model, 64);
+    mesh.is_static = is_static != 0;
+    const uint32_t mesh_id = (uint32_t)c->meshes.size();
+    const size_t keep_pos = c->h_pos.size(), keep_attr = c->h_attr.size(), keep_idx = c->h_idx.size(), keep_prims = c->prims.size();
+    auto rollback = [&](int code, const char* msg) {
+        c->h_pos.resize(keep_pos); c->h_attr.resize(keep_attr); c->h_idx.resize(keep_idx); c->prims.resize(keep_prims);
+        return fail(c, code, msg);
+    };
+    for (uint32_t pi = 0; pi < count; pi++) {
+        const rdr_primitive_desc& d = descs[pi];
+        if (d.mode != 4) return rollback(RDR_ERR_UNSUPPORTED, "add_mesh: only triangle lists are supported");
+        const rdr_vertex_attribute* at[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (uint32_t a = 0; a < d.attribute_count; a++) {
+            const rdr_vertex_attribute& va = d.attributes[a];
+            if (va.name > RDR_ATTR_BITANGENT) continue;
+            if (va.buffer >= c->buffers.size()) return rollback(RDR_ERR_INVALID, "add_mesh: bad buffer id");
+            at[va.name] = &va;
+        }
+        if (!at[RDR_ATTR_POSITION]) return rollback(RDR_ERR_INVALID, "add_mesh: POSITION missing");
+        const size_t nv = (size_t)at[RDR_ATTR_POSITION]->count;
+        HostPrim hp;
+        hp.first_vertex = (uint32_t)(c->h_pos.size() / 4);
+        hp.first_index = (uint32_t)c->h_idx.size();
+        hp.n_vertices = (uint32_t)nv;
+        c->h_pos.resize(c->h_pos.size() + nv * 4);
+        c->h_attr.resize(c->h_attr.size() + nv);
+        float* pos = c->h_pos.data() + (size_t)hp.first_vertex * 4;
+        DVertexAttr* attr = c->h_attr.data() + hp.first_vertex;
+        memset(attr, 0, nv * sizeof(DVertexAttr));
+        // reads `comps` components of element i of an attribute as floats
+        auto fetch = [&](const rdr_vertex_attribute* va, size_t i, int comps, float* o) -> bool {
+            const size_t vs = value_size(va->value_type);
+            const int have = (int)va->container + 1;
+            const size_t stride = va->stride ? (size_t)va->stride : vs * have;
+            const size_t off = (size_t)va->offset + i * stride;
+            const std::vector<uint8_t>& buf = c->buffers[va->buffer];
+            if (off + vs * std::min(comps, have) > buf.size()) return false;
+            const bool norm = va->name == RDR_ATTR_TEXCOORD_0 && va->value_type != RDR_FLOAT;
+            for (int k = 0; k < comps; k++) o[k] = k < have ? component_as_float(&buf[off + k * vs], va->value_type, norm) : 0.0f;
+            return true;
+        };
+        for (size_t i = 0; i < nv; i++) {
+            float v[4];
+            if (!fetch(at[RDR_ATTR_POSITION], i, 3, v)) return rollback(RDR_ERR_INVALID, "add_mesh: POSITION out of range");
+            pos[i * 4] = v[0]; pos[i * 4 + 1] = v[1]; pos[i * 4 + 2] = v[2]; pos[i * 4 + 3] = 1.0f;
+            if (at[RDR_ATTR_NORMAL]) {
+                if (!fetch(at[RDR_ATTR_NORMAL], i, 3, v)) return rollback(RDR_ERR_INVALID, "add_mesh: NORMAL out of range");
+                attr[i].nx = v[0]; attr[i].ny = v[1]; attr[i].nz = v[2];
+            }
+            if (at[RDR_ATTR_TEXCOORD_0]) {
+                if (!fetch(at[RDR_ATTR_TEXCOORD_0], i, 2, v)) return rollback(RDR_ERR_INVALID, "add_mesh: TEXCOORD_0 out of range");
+                attr[i].u = v[0]; attr[i].v = v[1];
+            }
+            if (at[RDR_ATTR_TANGENT]) {
+                if (!fetch(at[RDR_ATTR_TANGENT], i, 4, v)) return rollback(RDR_ERR_INVALID, "add_mesh: TANGENT out of range");
+                attr[i].tx = v[0]; attr[i].ty = v[1]; attr[i].tz = v[2];
+                if (at[RDR_ATTR_BITANGENT]) {
+                    float b[4];
+                    if (!fetch(at[RDR_ATTR_BITANGENT], i, 3, b)) return rollback(RDR_ERR_INVALID, "add_mesh: BITANGENT out of range");
+                    attr[i].bx = b[0]; attr[i].by = b[1]; attr[i].bz = b[2];
+                } else {  // main.cpp:93
+                    const vec3 bt = mulf(cross(make3(attr[i].nx, attr[i].ny, attr[i].nz), make3(v[0], v[1], v[2])), v[3]);
+                    attr[i].bx = bt.x; attr[i].by = bt.y; attr[i].bz = bt.z;
+                }
+            }
+        }
+        size_t n_idx;
+        if (d.indices.buffer != RDR_INVALID_ID) {
+            if (d.indices.buffer >= c->buffers.size()) return rollback(RDR_ERR_INVALID, "add_mesh: bad index buffer id");
+            const std::vector<uint8_t>& buf = c->buffers[d.indices.buffer];
+            const uint32_t it = d.indices.index_type;
+            if (it != RDR_UINT8 && it != RDR_UINT16 && it != RDR_UINT32) return rollback(RDR_ERR_UNSUPPORTED, "add_mesh: index type");
+            const size_t is = value_size(it);
+            if ((size_t)d.indices.offset + is * d.indices.count > buf.size()) return rollback(RDR_ERR_INVALID, "add_mesh: indices out of range");
+            n_idx = (size_t)d.indices.count / 3 * 3;
+            c->h_idx.resize(hp.first_index + n_idx);
+            for (size_t i = 0; i < n_idx; i++) {
+                const uint8_t* q = &buf[(size_t)d.indices.offset + i * is];
+                uint32_t v = 0;
+                if (it == RDR_UINT8) v = q[0];
+                else if (it == RDR_UINT16) { uint16_t t; memcpy(&t, q, 2); v = t; }
+                else memcpy(&v, q, 4);
+                if (v >= nv) return rollback(RDR_ERR_INVALID, "add_mesh: index beyond vertex count");
+                c->h_idx[hp.first_index + i] = v;
+            }
+        } else {
+            n_idx = nv / 3 * 3;
+            c->h_idx.resize(hp.first_index + n_idx);
+            for (size_t i = 0; i < n_idx; i++) c->h_idx[hp.first_index + i] = (uint32_t)i;
+        }
+        hp.tri_count = (uint32_t)(n_idx / 3);
+        // re-take the pointers: h_idx growth does not move them, but keep it obvious
+        pos = c->h_pos.data() + (size_t)hp.first_vertex * 4;
+        attr = c->h_attr.data() + hp.first_vertex;
+        if (!at[RDR_ATTR_TANGENT]) {
+            // MeshPrimitive::calculateTangents, indexed form (Mesh.cpp:5-52)
+            const uint32_t* ix = c->h_idx.data() + hp.first_index;
+            for (size_t i = 0; i + 2 < n_idx; i += 3) {
+                const uint32_t a = ix[i], b = ix[i + 1], cc = ix[i + 2];
+                const vec3 pa = make3(pos[a * 4], pos[a * 4 + 1], pos[a * 4 + 2]);
+                const vec3 e1 = sub(make3(pos[b * 4], pos[b * 4 + 1], pos[b * 4 + 2]), pa), e2 = sub(make3(pos[cc * 4], pos[cc * 4 + 1], pos[cc * 4 + 2]), pa);
+                const float s1 = attr[b].u - attr[a].u, s2 = attr[cc].u - attr[a].u, t1 = attr[b].v - attr[a].v, t2 = attr[cc].v - attr[a].v;
+                const float f = 1.0f / (s1 * t2 - s2 * t1);
+                const vec3 sdir = make3((t2 * e1.x - t1 * e2.x) * f, (t2 * e1.y - t1 * e2.y) * f, (t2 * e1.z - t1 * e2.z) * f);
+                const uint32_t vs[3] = {a, b, cc};
+                for (uint32_t vtx : vs) {
+                    attr[vtx].tx = sdir.x; attr[vtx].ty = sdir.y; attr[vtx].tz = sdir.z;
+                    const vec3 bt = cross(make3(attr[vtx].nx, attr[vtx].ny, attr[vtx].nz), sdir);
+                    attr[vtx].bx = bt.x; attr[vtx].by = bt.y; attr[vtx].bz = bt.z;
+                }
+            }
+        }
+        hp.bb_min = make3(d.bb_min[0], d.bb_min[1], d.bb_min[2]);
+        hp.bb_max = make3(d.bb_max[0], d.bb_max[1], d.bb_max[2]);
+        vec3 bc = make3(0, 0, 0);  // calculateBarycenter (Mesh.cpp:77-86)
+        for (size_t i = 0; i < nv; i++) bc = add(bc, make3(pos[i * 4], pos[i * 4 + 1], pos[i * 4 + 2]));
+        bc = make3(bc.x / (float)nv, bc.y / (float)nv, bc.z / (float)nv);
+        const vec4 bch = mat_mul_vec(mesh.model, vec4{bc.x, bc.y, bc.z, 1.0f});
+        hp.barycenter = make3(bch.x / bch.w, bch.y / bch.w, bch.z / bch.w);
+        hp.mat = d.material;
+        const uint32_t tex_ids[5] = {hp.mat.albedo_texture, hp.mat.normal_texture, hp.mat.metal_roughness_texture, hp.mat.ao_texture, hp.mat.emissive_texture};
+        for (uint32_t t : tex_ids)
+            if (t != RDR_INVALID_ID && t >= c->textures.size()) return rollback(RDR_ERR_INVALID, "add_mesh: bad texture id");
+        hp.mesh = mesh_id;
+        c->prims.push_back(hp);
+    }
+    c->meshes.push_back(mesh);
+    c->geometry_dirty = true;
+    if (out_mesh_id) *out_mesh_id = mesh_id;
+    return RDR_OK;
+}
+
+int rdr_set_mesh_transform(rdr_ctx* c, uint32_t mesh_id, const float model[16]) {
+    if (!c || !model || mesh_id >= c->meshes.size()) return fail(c, RDR_ERR_INVALID, "set_mesh_transform: bad argument");
+    memcpy(c->meshes[mesh_id].model.m, model, 64);
+    return RDR_OK;
+}
+
+int rdr_set_lights(rdr_ctx* c, const rdr_point_light* lights, uint32_t count, const rdr_directional_light* dl) {
+    if (!c || !dl || (count && !lights)) return fail(c, RDR_ERR_INVALID, "set_lights: bad argument");
+    c->lights.clear();
+    for (uint32_t i = 0; i < count; i++) {
+        HostLight l;
+        l.point = make3(lights[i].point[0], lights[i].point[1], lights[i].point[2]);
+        l.intensity = make3(lights[i].intensity[0], lights[i].intensity[1], lights[i].intensity[2]);
+        l.flags = lights[i].flags & RDR_POINT_LIGHT_CAST_SHADOWS;
+        l.slot = 0xFFFF;
+        c->lights.push_back(l);
+    }
+    c->dir_light = *dl;
+    c->lights_set = true;
+    compute_cascade_splits(c);
+    return RDR_OK;
+}
+
+int rdr_set_environment_map(rdr_ctx* c, const float* const faces[6], uint32_t w, uint32_t h) {
+    if (!c || !faces || w == 0 || w != h) return fail(c, RDR_ERR_INVALID, "set_environment_map: faces must be square");
+    for (int f = 0; f < 6; f++) if (!faces[f]) return fail(c, RDR_ERR_INVALID, "set_environment_map: null face");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t face_px = (size_t)w * w;
+    HIP_TRY(c->d_env.ensure(6 * face_px * 4));
+    DevBuf staging;
+    HIP_TRY(staging.ensure(face_px * 16));
+    for (int f = 0; f < 6; f++) {
+        HIP_TRY(hipMemcpyAsync(staging.p, faces[f], face_px * 16, hipMemcpyHostToDevice, c->stream));
+        launch_env_pack(c->stream, staging.p, c->d_env.as<uint32_t>() + f * face_px, (uint32_t)face_px);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    staging.release();
+    memset(&c->env, 0, sizeof c->env);
+    c->env.texels = c->d_env.as<uint32_t>(); c->env.res = w; c->env.levels = 1;
+    // irradiance: 256^2 per face (VulkanRenderer.h:220)
+    {
+        const int res = 256;
+        HIP_TRY(c->d_irradiance.ensure((size_t)6 * res * res * 4));
+        IrradianceTables tb;
+        const float PI = 3.14159265359f;
+        const int nSamples = 24;
+        const float stepRads = 2 * PI / nSamples;
+        for (int i = 0; i < 24; i++) { const float phi = i * stepRads; tb.cos_phi[i] = cosf(phi); tb.sin_phi[i] = sinf(phi); }
+        for (int j = 0; j < 6; j++) { const float theta = j * stepRads; tb.sin_theta[j] = sinf(theta); tb.cos_theta[j] = cosf(theta); }
+        launch_bake_irradiance(c->stream, c->env, c->d_irradiance.as<uint32_t>(), res, tb);
+        memset(&c->irradiance, 0, sizeof c->irradiance);
+        c->irradiance.texels = c->d_irradiance.as<uint32_t>(); c->irradiance.res = res; c->irradiance.levels = 1;
+    }
+    // GGX prefilter: 512^2, 10 levels, roughness = level / 9 (VulkanRenderer.h:225, …Environment.cpp:350-360)
+    {
+        const int base = 512, levels = 10;
+        size_t off = 0;
+        memset(&c->prefiltered, 0, sizeof c->prefiltered);
+        for (int l = 0; l < levels; l++) { c->prefiltered.level_offset[l] = (uint32_t)off; off += (size_t)6 * (base >> l) * (base >> l); }
+        HIP_TRY(c->d_prefiltered.ensure(off * 4));
+        std::vector<float> trig(256);
+        const float PI = 3.14159265359f;
+        for (int i = 0; i < 128; i++) {
+            const float xi_x = (float)i / (float)128;
+            const float phi = 2.0f * PI * xi_x;
+            trig[i] = cosf(phi); trig[128 + i] = sinf(phi);
+        }
+        HIP_TRY(c->d_trig.ensure(256 * 4));
+        HIP_TRY(hipMemcpyAsync(c->d_trig.p, trig.data(), 256 * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int l = 0; l < levels; l++)
+            launch_bake_prefilter(c->stream, c->env, c->d_prefiltered.as<uint32_t>() + c->prefiltered.level_offset[l], base >> l, (float)l / 9,
+                                  c->d_trig.as<float>());
+        c->prefiltered.texels = c->d_prefiltered.as<uint32_t>(); c->prefiltered.res = base; c->prefiltered.levels = levels;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return RDR_OK;
+}
+
+int rdr_set_brdf_lut(rdr_ctx* c, const uint8_t* px, uint32_t w, uint32_t h, uint32_t channels) {
+    if (!c || !px || w == 0 || h == 0 || (channels != 3 && channels != 4)) return fail(c, RDR_ERR_INVALID, "set_brdf_lut: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint8_t> rgba((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        for (int k = 0; k < 3; k++) rgba[i * 4 + k] = px[i * channels + k];
+        rgba[i * 4 + 3] = channels == 4 ? px[i * 4 + 3] : 255;
+    }
+    HIP_TRY(c->d_lut.ensure(rgba.size()));
+    HIP_TRY(hipMemcpy(c->d_lut.p, rgba.data(), rgba.size(), hipMemcpyHostToDevice));
+    c->lut_w = w; c->lut_h = h;
+    return RDR_OK;
+}
+
+int rdr_set_camera(rdr_ctx* c, const rdr_camera* cam) {
+    if (!c || !cam) return fail(c, RDR_ERR_INVALID, "set_camera: null");
+    c->camera.type = cam->type;
+    c->camera.position = make3(cam->position[0], cam->position[1], cam->position[2]);
+    c->camera.euler = make3(cam->euler[0], cam->euler[1], cam->euler[2]);
+    c->camera.near_plane = cam->near_plane; c->camera.far_plane = cam->far_plane;
+    c->camera.fov_or_height = cam->fov_or_height; c->camera.aspect = cam->aspect_ratio;
+    return RDR_OK;
+}
+
+int rdr_set_exposure_bias(rdr_ctx* c, float bias, float gamma) {
+    if (!c) return RDR_ERR_INVALID;
+    c->settings.exposure_bias = bias; c->settings.gamma = gamma;
+    return RDR_OK;
+}
+
+int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int out_is_device, float* out_avg) {
+    if (!c) return RDR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t W = c->W, H = c->H, S = c->settings.msaa;
+    const size_t n = (size_t)W * H;
+    RDR_TRY(upload_scene(c));
+    RDR_TRY(ensure_post_targets(c));
+    HIP_TRY(c->d_depth.ensure(n * S * 4));
+    HIP_TRY(c->d_vis.ensure(n * S * 4));
+    c->stats = rdr_frame_stats{};
+    HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    const vec3 cam_pos = c->camera.position;
+    const mat4 viewproj = c->camera.view_proj();
+
+    // ---- shadow views + main opaque view, rasterised as one batch
+    Batch b;
+    if (c->lights_set) {
+        RDR_TRY(point_shadow_views(c, cam_pos, b));
+        RDR_TRY(cascade_views(c, b));
+    }
+    std::vector<uint32_t> opaque, non_opaque;
+    for (uint32_t p = 0; p < c->prims.size(); p++) (c->prims[p].mat.alpha_mode == RDR_ALPHA_OPAQUE ? opaque : non_opaque).push_back(p);
+    const uint32_t main_view = (uint32_t)b.views.size();
+    b.views.push_back(make_view(c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), W, H, S, 2, 0));
+    const size_t first_main_draw = b.draws.size();
+    append_draws(c, opaque, viewproj, cam_pos, SORT_FRONT_TO_BACK, main_view, b.draws);
+    c->main_draws.assign(b.draws.begin() + first_main_draw, b.draws.end());
+    std::vector<DDraw> blended;
+    append_draws(c, non_opaque, viewproj, cam_pos, SORT_BACK_TO_FRONT, 0, blended);
+    c->stats.draws_main = (uint32_t)(c->main_draws.size() + blended.size());
+    RDR_TRY(raster_batch(c, b));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+
+    // ---- frame constants
+    {
+        DFrame fr;
+        memset(&fr, 0, sizeof fr);
+        fr.W = W; fr.H = H; fr.samples = S; fr.n_lights = (uint32_t)c->lights.size();
+        fr.inv2W = 2.0f / (float)W; fr.inv2H = 2.0f / (float)H;
+        fr.cam[0] = cam_pos.x; fr.cam[1] = cam_pos.y; fr.cam[2] = cam_pos.z;
+        const mat4 inv = mat_inverse(viewproj);
+        memcpy(fr.inv_viewproj, inv.m, 64);
+        fr.n_cascades = c->settings.directional_shadow_cascade_levels;
+        for (uint32_t i = 0; i < fr.n_cascades; i++) memcpy(fr.csm_viewproj[i], c->csm_viewproj[i].m, 64);
+        fr.dir_res = c->settings.directional_shadow_map_resolution; fr.point_res = c->settings.point_shadow_map_resolution;
+        fr.lights_set = c->lights_set ? 1u : 0u;
+        if (c->lights_set) {
+            const quat q = {c->dir_light.orientation_wxyz[0], c->dir_light.orientation_wxyz[1], c->dir_light.orientation_wxyz[2], c->dir_light.orientation_wxyz[3]};
+            const vec3 L = normalize(quat_rotate(q, make3(0.0f, 0.0f, 1.0f)));  // VulkanRenderer.cpp:263 + pbr.frag:179-180
+            fr.dir_L[0] = L.x; fr.dir_L[1] = L.y; fr.dir_L[2] = L.z;
+            memcpy(fr.dir_I, c->dir_light.intensity, 12);
+        }
+        fr.dir_shadow = c->d_dir_shadow.as<float>(); fr.point_shadow = c->d_point_shadow.as<float>();
+        std::vector<DPointLight> dl(std::max<size_t>(c->lights.size(), 1));
+        for (size_t i = 0; i < c->lights.size(); i++) {
+            const HostLight& l = c->lights[i];
+            dl[i] = DPointLight{l.point.x, l.point.y, l.point.z, l.intensity.x, l.intensity.y, l.intensity.z, l.flags, l.slot};
+        }
+        HIP_TRY(c->d_lights.ensure(dl.size() * sizeof(DPointLight)));
+        fr.lights = c->d_lights.as<DPointLight>();
+        fr.env = c->env; fr.irradiance = c->irradiance; fr.prefiltered = c->prefiltered;
+        fr.lut = c->d_lut.as<uint8_t>(); fr.lut_w = c->lut_w; fr.lut_h = c->lut_h;
+        fr.textures = c->d_textures.as<DTexture>(); fr.prims = c->d_prims.as<DPrim>();
+        fr.pos = c->d_pos.as<float4>(); fr.attr = c->d_attr.as<DVertexAttr>(); fr.idx = c->d_idx.as<uint32_t>();
+        fr.srgb_decode = c->d_tables.as<float>(); fr.unorm_decode = c->d_tables.as<float>() + 256;
+        fr.tex_white = 0; fr.tex_normal = 1;
+        // the staging buffer is free again: bin_batch synchronised after its uploads
+        const size_t sz_l = dl.size() * sizeof(DPointLight);
+        HIP_TRY(c->h_stage.ensure(sizeof(DFrame) + sz_l + (c->main_draws.size() + 1) * (sizeof(DDraw) + 4) + 64));
+        uint8_t* st = c->h_stage.as<uint8_t>();
+        memcpy(st, &fr, sizeof fr);
+        memcpy(st + sizeof fr, dl.data(), sz_l);
+        HIP_TRY(hipMemcpyAsync(c->d_frame.p, st, sizeof fr, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_lights.p, st + sizeof fr, sz_l, hipMemcpyHostToDevice, c->stream));
+        // main-view draws + their first triangle ids, for the shading kernels
+        const size_t nd = c->main_draws.size();
+        uint8_t* st2 = st + sizeof fr + sz_l;
+        std::vector<uint32_t> first_tri(nd + 1, 0);
+        for (size_t i = 0; i < nd; i++) first_tri[i] = c->main_draws[i].first_tri_id;
+        if (nd) memcpy(st2, c->main_draws.data(), nd * sizeof(DDraw));
+        memcpy(st2 + nd * sizeof(DDraw), first_tri.data(), (nd + 1) * 4);
+        HIP_TRY(c->d_draws.ensure(std::max<size_t>(nd, 1) * sizeof(DDraw)));
+        HIP_TRY(c->d_first_tri.ensure((nd + 1) * 4));
+        if (nd) HIP_TRY(hipMemcpyAsync(c->d_draws.p, st2, nd * sizeof(DDraw), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_first_tri.p, st2 + nd * sizeof(DDraw), (nd + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    }
+
+    // ---- opaque shading + skybox
+    const bool have_blend = !blended.empty();
+    void* color_target = c->d_hdr.p;
+    if (S == 4 && have_blend) { HIP_TRY(c->d_samples.ensure(n * 4 * 8)); color_target = c->d_samples.p; }
+    launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>(), c->d_first_tri.as<uint32_t>(),
+                        (uint32_t)c->main_draws.size(), c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
+                        (S == 4 && have_blend) ? c->d_samples.p : nullptr, W, H);
+    HIP_TRY(hipGetLastError());
+
+    // ---- blended draws, back to front
+    if (have_blend) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // d_draws / staging are about to be reused by the blend batch
+        Batch bb;
+        bb.views.push_back(make_view(c->d_depth.as<float>(), nullptr, W, H, S, 2, 1));
+        bb.draws = blended;
+        uint32_t n_tiles = 0;
+        int cur = 0;
+        RDR_TRY(bin_batch(c, bb, &n_tiles, &cur));
+        c->stats.views -= 1;  // the blended draws belong to the main view, already counted
+        launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>(), c->d_draws.as<DDraw>(),
+                            c->d_first_tri.as<uint32_t>(), (uint32_t)bb.draws.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                            c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, color_target);
+        if (S == 4) launch_resolve4(c->stream, c->d_samples.p, c->d_hdr.p, (uint32_t)n);
+        HIP_TRY(hipGetLastError());
+    }
+
+    // ---- bloom, tonemap, luminance
+    if (c->have_frame && (!fp || fp->exposure_mode == 0)) RDR_TRY(rdr_synchronize(c));  // previous frame's luminance
+    const float exposure = compute_exposure(c, fp);
+    enqueue_post(c, exposure);
+    HIP_TRY(hipGetLastError());
+    c->have_frame = true;
+    c->stats.exposure = exposure;
+    HIP_TRY(c->h_read.ensure(64));
+    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 16, c->d_lum.as<float>() + 256, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 32, c->d_counters.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    if (out_rgba8) HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+    // With a device destination the call only enqueues; rdr_synchronize() (or the next frame's first
+    // internal synchronisation) picks up the luminance and the counters.
+    if (out_is_device && out_rgba8) return RDR_OK;
+    RDR_TRY(rdr_synchronize(c));
+    if (out_avg) *out_avg = c->last_avg_log_lum;
+    return RDR_OK;
+}
+
+int rdr_synchronize(rdr_ctx* c) {
+    if (!c) return RDR_ERR_INVALID;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->have_frame && c->h_read.p) {
+        memcpy(&c->last_avg_log_lum, c->h_read.as<uint8_t>() + 16, 4);
+        uint32_t binned; memcpy(&binned, c->h_read.as<uint8_t>() + 32, 4);
+        c->stats.triangles_binned = binned;
+        c->stats.avg_log_luminance = c->last_avg_log_lum;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_geometry = ms;
+        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_shade = ms;
+        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_bloom = ms;
+        if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->stats.ms_tonemap = ms;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->stats.ms_total = ms;
+    }
+    return RDR_OK;
+}
+
+int rdr_get_frame_stats(rdr_ctx* c, rdr_frame_stats* out) {
+    if (!c || !out) return RDR_ERR_INVALID;
+    *out = c->stats;
+    return RDR_OK;
+}
+
+static int read_back(rdr_ctx* c, void* dst, const void* src, size_t bytes) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return RDR_OK;
+}
+
+int rdr_read_depth(rdr_ctx* c, float* out) {
+    if (!c || !out || !c->have_frame) return fail(c, RDR_ERR_INVALID, "read_depth: no frame");
+    return read_back(c, out, c->d_depth.p, (size_t)c->W * c->H * c->settings.msaa * 4);
+}
+int rdr_read_visibility(rdr_ctx* c, uint32_t* out) {
+    if (!c || !out || !c->have_frame) return fail(c, RDR_ERR_INVALID, "read_visibility: no frame");
+    return read_back(c, out, c->d_vis.p, (size_t)c->W * c->H * c->settings.msaa * 4);
+}
+int rdr_read_directional_shadow(rdr_ctx* c, uint32_t index, float* out) {
+    if (!c || !out || !c->have_frame || !c->lights_set || index >= c->settings.directional_shadow_cascade_levels) return fail(c, RDR_ERR_INVALID, "read_directional_shadow");
+    const size_t px = (size_t)c->settings.directional_shadow_map_resolution * c->settings.directional_shadow_map_resolution;
+    return read_back(c, out, c->d_dir_shadow.as<float>() + index * px, px * 4);
+}
+int rdr_read_point_shadow(rdr_ctx* c, uint32_t slot, uint32_t face, float* out) {
+    const size_t px = c ? (size_t)c->settings.point_shadow_map_resolution * c->settings.point_shadow_map_resolution : 0;
+    if (!c || !out || face >= 6 || slot >= c->settings.point_shadow_map_count || !c->d_point_shadow.p) return fail(c, RDR_ERR_INVALID, "read_point_shadow");
+    return read_back(c, out, c->d_point_shadow.as<float>() + ((size_t)slot * 6 + face) * px, px * 4);
+}
+int rdr_read_hdr(rdr_ctx* c, float* out) {
+    if (!c || !out || !c->have_post) return fail(c, RDR_ERR_INVALID, "read_hdr: nothing rendered");
+    const size_t n = (size_t)c->W * c->H;
+    std::vector<uint16_t> tmp(n * 4);
+    RDR_TRY(read_back(c, tmp.data(), c->d_hdr.p, n * 8));
+    for (size_t i = 0; i < n * 4; i++) out[i] = half_bits_to_float(tmp[i]);
+    return RDR_OK;
+}
+static float ufloat_decode(uint32_t v, int mb) {
+    const uint32_t e = v >> mb, m = v & ((1u << mb) - 1u);
+    uint32_t bits;
+    if (e == 0) return (float)m * ldexpf(1.0f, -14 - mb);
+    if (e == 31) bits = 0x7F800000u | (m << (23 - mb));
+    else bits = ((e + 112u) << 23) | (m << (23 - mb));
+    float f; memcpy(&f, &bits, 4); return f;
+}
+static void unpack_rgb(const std::vector<uint32_t>& src, float* out) {
+    for (size_t i = 0; i < src.size(); i++) {
+        out[i * 3] = ufloat_decode(src[i] & 0x7FFu, 6);
+        out[i * 3 + 1] = ufloat_decode((src[i] >> 11) & 0x7FFu, 6);
+        out[i * 3 + 2] = ufloat_decode(src[i] >> 22, 5);
+    }
+}
+int rdr_read_bloom(rdr_ctx* c, uint32_t level, float* out) {
+    if (!c || !out || !c->have_post || level >= 6) return fail(c, RDR_ERR_INVALID, "read_bloom");
+    std::vector<uint32_t> tmp((size_t)c->bloom_w[level] * c->bloom_h[level]);
+    RDR_TRY(read_back(c, tmp.data(), c->d_bloom.as<uint32_t>() + c->bloom_offset[level], tmp.size() * 4));
+    unpack_rgb(tmp, out);
+    return RDR_OK;
+}
+int rdr_read_log_luminance(rdr_ctx* c, float* out) {
+    if (!c || !out || !c->have_post) return fail(c, RDR_ERR_INVALID, "read_log_luminance");
+    return read_back(c, out, c->d_loglum.p, (size_t)c->W * c->H * 4);
+}
+int rdr_read_env_cube(rdr_ctx* c, int which, uint32_t level, float* out) {
+    if (!c || !out) return RDR_ERR_INVALID;
+    const DCube& cube = which == 0 ? c->env : (which == 1 ? c->irradiance : c->prefiltered);
+    if (!cube.res || level >= cube.levels) return fail(c, RDR_ERR_INVALID, "read_env_cube");
+    const uint32_t r = std::max(1u, cube.res >> level);
+    std::vector<uint32_t> tmp((size_t)6 * r * r);
+    RDR_TRY(read_back(c, tmp.data(), cube.texels + cube.level_offset[level], tmp.size() * 4));
+    unpack_rgb(tmp, out);
+    return RDR_OK;
+}
+int rdr_read_cascades(rdr_ctx* c, float* vp, float* depth) {
+    if (!c || !vp || !depth || !c->lights_set || !c->have_frame) return fail(c, RDR_ERR_INVALID, "read_cascades");
+    for (uint32_t i = 0; i < 4; i++) {
+        if (i < c->settings.directional_shadow_cascade_levels) { memcpy(vp + 16 * i, c->csm_viewproj[i].m, 64); depth[i] = c->cascade_camera_depths[i]; }
+        else { memset(vp + 16 * i, 0, 64); depth[i] = 0.0f; }
+    }
+    return RDR_OK;
+}
+int rdr_read_image_level(rdr_ctx* c, uint32_t image, uint32_t level, uint8_t* out, uint32_t* ow, uint32_t* oh) {
+    if (!c || image >= c->images.size() || level >= c->images[image].levels) return fail(c, RDR_ERR_INVALID, "read_image_level");
+    const HostImage& img = c->images[image];
+    const uint32_t w = std::max(1u, img.w >> level), h = std::max(1u, img.h >> level);
+    if (ow) *ow = w;
+    if (oh) *oh = h;
+    if (out) return read_back(c, out, img.pixels.as<uint32_t>() + img.level_offset[level], (size_t)w * h * 4);
+    return RDR_OK;
+}
+
+int rdr_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_rgba8, float* out_avg) {
+    if (!c || !hdr) return fail(c, RDR_ERR_INVALID, "post_process: null");
+    HIP_TRY(hipSetDevice(c->device));
+    RDR_TRY(ensure_post_targets(c));
+    const size_t n = (size_t)c->W * c->H;
+    // quantise to RGBA16F on the host (round to nearest even) exactly like the colour attachment would store it
+    std::vector<uint16_t> h16(n * 4);
+    for (size_t i = 0; i < n * 4; i++) {
+        const _Float16 q = (_Float16)hdr[i];
+        memcpy(&h16[i], &q, 2);
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_hdr.p, h16.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < 6; i++) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
+    enqueue_post(c, exposure);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, c->d_out.p, n * 4, hipMemcpyDeviceToHost));
+    if (out_avg) HIP_TRY(hipMemcpy(out_avg, c->d_lum.as<float>() + 256, 4, hipMemcpyDeviceToHost));
+    return RDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Plain-data structures shared by the host side of the library and its HIP
+// kernels: everything a kernel reads from HBM that is not a pixel or a vertex.
+#pragma once
+#include <stdint.h>
+
+#define RDR_TILE 16             // raster tile edge in pixels (one 256-thread block, 4 waves of 8x8)
+#define RDR_MAX_POLY 9          // a triangle cut by 6 planes has at most 9 vertices
+#define RDR_MAX_CASCADES 4
+#define RDR_MAX_TEX_LEVELS 16
+#define RDR_PAIR_INVALID 0xFFFFFFFFu
+
+// Material block of one primitive (PBRInfo + AlphaInfo of the reference,
+// read by pbr.frag:21-37) plus its five texture slots.
+struct DMaterial {
+    float base_color[4];
+    float emissive[4];
+    float metallic, roughness, ao;
+    float alpha_cutoff;
+    int32_t alpha_mode;
+    uint32_t tex[5];  // albedo, normal, metalRough, ao, emissive (indices into DTexture table)
+    uint32_t _pad[2];
+};
+
+// One mesh primitive in the geometry arena.
+struct DPrim {
+    uint32_t first_vertex;  // into pos[] / attr[]
+    uint32_t first_index;   // into idx[]
+    uint32_t tri_count;
+    uint32_t _pad;
+    DMaterial mat;
+};
+
+// Per-vertex shading attributes, the reference's Vertex (Vertex.h:8-12) without the position.
+struct DVertexAttr {
+    float nx, ny, nz;
+    float tx, ty, tz;
+    float bx, by, bz;
+    float u, v;
+    float _pad;
+};  // 48 bytes
+
+// One texture = image (all mip levels, RGBA8, level-major) + sampler state.
+struct DTexture {
+    const uint8_t* base;
+    uint32_t w, h, levels;
+    uint32_t flags;  // bit0 sRGB, bits 4..5 wrap_u, bits 8..9 wrap_v
+    uint32_t level_offset[RDR_MAX_TEX_LEVELS];  // in texels
+};
+
+// One raster view (a shadow-map face, a cascade, or the main camera).
+struct DView {
+    float* depth;        // [samples][h][w]
+    uint32_t* vis;       // same layout, or null for depth-only views
+    uint32_t w, h;
+    uint32_t samples;    // 1 or 4
+    uint32_t cull;       // 0 none, 1 front, 2 back
+    uint32_t tiles_x, tiles_y;
+    uint32_t tile_base;  // first global tile id of this view
+    uint32_t load;       // 0: clear depth to 1.0 first, 1: keep what the target holds
+};
+
+// One draw = one primitive seen from one view.
+struct DDraw {
+    float mvp[16];
+    float model[16];
+    uint32_t view;
+    uint32_t prim;
+    uint32_t first_instance;  // global index of its first triangle instance in this batch
+    uint32_t first_tri_id;    // running triangle index inside its view (the visibility id)
+};
+
+// Output of triangle set-up: the snapped clip polygon and its depth plane.
+struct DTriRec {
+    int32_t X[RDR_MAX_POLY];  // 1/256 px, oriented so the interior has positive edge functions
+    int32_t Y[RDR_MAX_POLY];
+    uint32_t n_view;          // n (low 8 bits, 0 = dropped) | view << 8
+    uint32_t id;              // visibility id
+    int16_t px0, py0, px1, py1;  // pixel bounding box, inclusive, clipped to the view
+    uint32_t _pad;
+    double dzdX, dzdY, z00;   // z(P) = dzdX*Px + dzdY*Py + z00, P in 1/256 px
+    uint32_t _pad2[2];
+};  // 128 bytes
+
+struct DPointLight {
+    float px, py, pz;
+    float ix, iy, iz;
+    uint32_t flags;
+    uint32_t slot;
+};
+
+struct DCube {
+    const uint32_t* texels;  // B10G11R11 packed, level-major, face-major inside a level
+    uint32_t res, levels;
+    uint32_t level_offset[12];
+};
+
+// Everything the shading kernels need for one frame.
+struct DFrame {
+    uint32_t W, H, samples, n_lights;
+    float inv2W, inv2H;
+    float cam[3];
+    float inv_viewproj[16];
+    float csm_viewproj[RDR_MAX_CASCADES][16];
+    uint32_t n_cascades, dir_res, point_res, lights_set;
+    float dir_L[3];          // normalised direction towards... exactly directionalLight.direction normalised
+    float dir_I[3];
+    const float* dir_shadow;    // [cascade][res][res]
+    const float* point_shadow;  // [slot*6+face][res][res]
+    const DPointLight* lights;
+    DCube env, irradiance, prefiltered;
+    const uint8_t* lut;  // RGBA8
+    uint32_t lut_w, lut_h;
+    const DTexture* textures;
+    const DPrim* prims;
+    const float4* pos;
+    const DVertexAttr* attr;
+    const uint32_t* idx;
+    const float* srgb_decode;   // 256 floats
+    const float* unorm_decode;  // 256 floats: i / 255
+    uint32_t tex_white, tex_normal;
+};
