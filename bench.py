@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the per-frame pixel pipeline on the Sponza-class scene at 4K.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One step = one full frame (point + cascaded shadow maps, PBR + IBL shading of the visibility buffer, sky,
+blended pass, bloom chain, tonemap, luminance) of the seeded synthetic stand-in for "Sponza 3840x2160,
+directional shadow + 16 point lights, IBL, bloom+tonemap" (BASELINE.json configs[1]); the real glTF asset does
+not exist offline. The scene is resident in HBM before the timed region and the finished RGBA8 frame stays on
+the device. With N > 1 every rank renders its own K frames of the camera path (frame-batch sharding, weak
+scaling) and the finished images are gathered to rank 0 over RCCL, overlapped with the next frame.
+
+Prints ONE JSON line on rank 0. `roofline` describes the dominant kernel (the shading kernel, bound by vector
+FP32 throughput: nothing in this path is a dense contraction, so the matrix cores are unused);
+`roofline_passes` adds the post-process chain against the HBM roof.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
+VALU_FP32_PEAK_TF = 157.3    # MI355X vector FP32 peak
+POST_BYTES_PER_PX = 50.65    # blit 12 + five downs 6.66 + five ups 11.99 + tonemap 20 (reference formats)
+
+
+def shade_flops_per_px(n_point_lights):
+    return 90.0 * (1 + n_point_lights) + 250.0
+
+
+def camera_for_frame(r, k):
+    """Camera path down the hall; frame k of the job."""
+    t = (k % 240) / 240.0
+    r.set_camera(position=(-11.0 + 6.0 * t, 2.2 + 0.3 * np.sin(6.283 * t), 0.6 - 0.8 * t), euler=(-0.05, -1.45 + 0.25 * np.sin(6.283 * t), 0.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--msaa", type=int, default=4)
+    ap.add_argument("--tex", type=int, default=1024)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from renderer_amd import scenes
+    from renderer_amd.api import Renderer, default_settings, load_hip_capi
+
+    W, H = a.width, a.height
+    r = Renderer(load_hip_capi(), W, H, default_settings(msaa=a.msaa), device=local_rank)
+    t0 = time.time()
+    info = scenes.sponza_like(r, tex_size=a.tex, detail=a.detail)
+    build_s = time.time() - t0
+    n_lights = 16
+
+    # finished frames stay on the device; two buffers so that the gather of frame k overlaps frame k+1
+    bufs = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    gather_lists = [[torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
+    pending = [None, None]
+
+    def step(k):
+        slot = k & 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+            pending[slot] = None
+        camera_for_frame(r, k * world + rank)
+        r.render_frame(exposure_mode=1, temporal_luminance=0.5, device_ptr=bufs[slot].data_ptr())
+        r.synchronize()
+        if dist:
+            pending[slot] = dist.gather(bufs[slot], gather_lists[slot], dst=0, async_op=True)
+
+    def drain():
+        for s in range(2):
+            if pending[s] is not None:
+                pending[s].wait()
+                pending[s] = None
+        torch.cuda.synchronize()
+
+    for k in range(a.warmup):
+        step(k)
+    drain()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    acc = {"shade_kernel": 0.0, "raster_kernel": 0.0, "geometry": 0.0, "shade": 0.0, "bloom": 0.0, "tonemap": 0.0, "total": 0.0}
+    last_stats = None
+    t_start = time.perf_counter()
+    for k in range(a.steps):
+        step(a.warmup + k)
+        s = r.frame_stats()
+        last_stats = s
+        acc["shade_kernel"] += s.ms_shade_kernel; acc["raster_kernel"] += s.ms_raster_kernel; acc["geometry"] += s.ms_geometry
+        acc["shade"] += s.ms_shade; acc["bloom"] += s.ms_bloom; acc["tonemap"] += s.ms_tonemap; acc["total"] += s.ms_total
+    drain()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # CPU restatement of the same frame on the host cores (reported baseline, not the target)
+        from oracle import orc
+        cores = int(os.environ.get("OMP_NUM_THREADS", str(os.cpu_count() or 1)))
+        ro = Renderer(orc.capi(), W, H, default_settings(msaa=a.msaa))
+        scenes.sponza_like(ro, tex_size=a.tex, detail=a.detail)
+        camera_for_frame(ro, 0)
+        ro.render_frame(exposure_mode=1, temporal_luminance=0.5)  # warm-up (renders the static point-shadow maps too)
+        times = []
+        for k in range(a.cpu_frames):
+            camera_for_frame(ro, 1 + k)
+            tc = time.perf_counter()
+            ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+            times.append(time.perf_counter() - tc)
+        cpu_baseline = {"value": 1.0 / float(np.median(times)), "unit": "frames/s", "cores": cores, "kind": "port",
+                        "sample": f"{a.cpu_frames} frames of the same {W}x{H} workload after 1 warm-up, OpenMP CPU restatement (not lavapipe)"}
+        ro.close()
+
+    if rank == 0:
+        K = a.steps
+        n_px = W * H
+        ms_step = elapsed * 1e3 / K
+        shade_ms = acc["shade_kernel"] / K
+        post_ms = (acc["bloom"] + acc["tonemap"]) / K
+        shade_flop = shade_flops_per_px(n_lights) * n_px
+        shade_tf = shade_flop / (shade_ms * 1e-3) / 1e12 if shade_ms > 0 else 0.0
+        post_gbs = POST_BYTES_PER_PX * n_px / (post_ms * 1e-3) / 1e9 if post_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec Sponza-class PBR+shadow+IBL+bloom @4K",
+            "value": K * world / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": a.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"sponza_like {W}x{H} msaa{a.msaa}, {info['triangles']} triangles / {info['primitives']} primitives, "
+                                   f"{a.tex}^2 textures, dir light 4x2048^2 cascades + 16 point lights (8 shadowed, 512^2 cubes), IBL, bloom+tonemap",
+                       "parallelism": f"frame-sharded x{world}, RCCL gather of RGBA8 frames to rank 0" if world > 1 else "single GPU",
+                       "lavapipe_oracle": "not available; CPU restatement used"},
+            "roofline": {"kernel": "k_shade_opaque", "bound": "valu_fp32", "achieved": shade_tf, "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": shade_tf / VALU_FP32_PEAK_TF, "traffic": None, "ms": shade_ms,
+                         "algorithmic": f"{shade_flops_per_px(n_lights):.0f} flop/px x {n_px} px"},
+            "roofline_passes": [
+                {"pass": "bloom chain + tonemap + luminance", "bound": "hbm", "achieved": post_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": post_gbs / HBM_PEAK_GBS, "ms": post_ms, "algorithmic": f"{POST_BYTES_PER_PX} B/px x {n_px} px"},
+            ],
+            "device_ms": {k: v / K for k, v in acc.items()},
+            "frame_counters": {"triangle_instances": int(last_stats.triangle_instances), "triangles_binned": int(last_stats.triangles_binned),
+                               "tile_pairs": int(last_stats.tile_pairs), "views": int(last_stats.views)},
+            "scene_build_s": build_s,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

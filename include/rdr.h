@@ -208,6 +208,8 @@ typedef struct rdr_frame_stats {
     float ms_total;
     float exposure;               /* value pushed to tonemap */
     float avg_log_luminance;
+    float ms_shade_kernel;        /* the opaque+sky shading kernel alone */
+    float ms_raster_kernel;       /* the tile raster kernel(s) of the main batch alone */
 } rdr_frame_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

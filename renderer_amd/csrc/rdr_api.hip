@@ -127,7 +127,7 @@ struct rdr_ctx {
 
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     rdr_frame_stats stats{};
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -392,8 +392,10 @@ int raster_batch(rdr_ctx* c, Batch& b) {
     RDR_TRY(bin_batch(c, b, &n_tiles, &cur));
     bool s1 = false, s4 = false;
     for (const DView& v : b.views) (v.samples == 4 ? s4 : s1) = true;
+    HIP_TRY(hipEventRecord(c->ev[8], c->stream));
     launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
                   c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, s1, s4);
+    HIP_TRY(hipEventRecord(c->ev[9], c->stream));
     HIP_TRY(hipGetLastError());
     return RDR_OK;
 }
@@ -619,7 +621,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     c->settings = *settings; c->W = width; c->H = height; c->device = device;
     memset(&c->dir_light, 0, sizeof c->dir_light);
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
-    for (int i = 0; i < 6 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    for (int i = 0; i < 10 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
     std::vector<float> tables(768);
     for (int i = 0; i < 256; i++) {
@@ -660,7 +662,7 @@ void rdr_destroy(rdr_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release();
-    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 10; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1044,9 +1046,11 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     const bool have_blend = !blended.empty();
     void* color_target = c->d_hdr.p;
     if (S == 4 && have_blend) { HIP_TRY(c->d_samples.ensure(n * 4 * 8)); color_target = c->d_samples.p; }
+    HIP_TRY(hipEventRecord(c->ev[6], c->stream));
     launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>(), c->d_first_tri.as<uint32_t>(),
                         (uint32_t)c->main_draws.size(), c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
                         (S == 4 && have_blend) ? c->d_samples.p : nullptr, W, H);
+    HIP_TRY(hipEventRecord(c->ev[7], c->stream));
     HIP_TRY(hipGetLastError());
 
     // ---- blended draws, back to front
@@ -1101,6 +1105,8 @@ int rdr_synchronize(rdr_ctx* c) {
         if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_bloom = ms;
         if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->stats.ms_tonemap = ms;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->stats.ms_total = ms;
+        if (hipEventElapsedTime(&ms, c->ev[6], c->ev[7]) == hipSuccess) c->stats.ms_shade_kernel = ms;
+        if (hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) c->stats.ms_raster_kernel = ms;
     }
     return RDR_OK;
 }
@@ -1210,7 +1216,7 @@ int rdr_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_
         memcpy(&h16[i], &q, 2);
     }
     HIP_TRY(hipMemcpyAsync(c->d_hdr.p, h16.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-    for (int i = 0; i < 6; i++) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
+    for (int i = 0; i < 10; i++) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
     enqueue_post(c, exposure);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -19,8 +19,18 @@ from .api import quat_look_at
 # ------------------------------------------------------------------ textures
 
 
+_NOISE_CACHE = {}
+
+
 def value_noise(size, seed, octaves=4, base=4):
-    """Tileable value noise in [0,1], float32 [size,size]."""
+    """Tileable value noise in [0,1], float32 [size,size] (cached, treat as read-only)."""
+    key = (size, seed, octaves, base)
+    if key not in _NOISE_CACHE:
+        _NOISE_CACHE[key] = _value_noise(size, seed, octaves, base)
+    return _NOISE_CACHE[key]
+
+
+def _value_noise(size, seed, octaves, base):
     rng = np.random.default_rng(seed)
     out = np.zeros((size, size), np.float32)
     amp, total = 1.0, 0.0
@@ -44,9 +54,26 @@ def to_u8(a):
     return np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
 
 
+_TEX_CACHE = {}
+
+
+def material_images(size, seed, tint=(1.0, 1.0, 1.0), metal_fraction=0.3, alpha=None):
+    """The five RGBA8 images of one procedural material (albedo sRGB, normal, metalRough, ao, emissive).
+    Cached per argument set so that several back ends fed the same scene share the arrays."""
+    key = (size, seed, tuple(float(t) for t in tint), float(metal_fraction), None if alpha is None else (alpha.shape, float(np.sum(alpha))))
+    if key not in _TEX_CACHE:
+        _TEX_CACHE[key] = _material_images(size, seed, tint, metal_fraction, alpha)
+    return _TEX_CACHE[key]
+
+
 def material_textures(r, size, seed, tint=(1.0, 1.0, 1.0), metal_fraction=0.3, alpha=None):
-    """Loads the five material textures of one procedural material; returns their texture ids
-    (albedo sRGB, normal, metalRough, ao, emissive)."""
+    """Loads the five material textures of one procedural material; returns their texture ids."""
+    imgs = material_images(size, seed, tint, metal_fraction, alpha)
+    fmts = (B.FORMAT_R8G8B8A8_SRGB, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM)
+    return [r.make_texture(r.load_image(img, fmt)) for img, fmt in zip(imgs, fmts)]
+
+
+def _material_images(size, seed, tint, metal_fraction, alpha):
     n0, n1, n2 = value_noise(size, seed), value_noise(size, seed + 1, base=8), value_noise(size, seed + 2, base=2)
     albedo = np.empty((size, size, 4), np.uint8)
     for k in range(3):
@@ -76,11 +103,7 @@ def material_textures(r, size, seed, tint=(1.0, 1.0, 1.0), metal_fraction=0.3, a
     em[..., 0] = np.where(spots, 255, 0)
     em[..., 1] = np.where(spots, 120, 0)
     em[..., 3] = 255
-    ids = []
-    for img, fmt in ((albedo, B.FORMAT_R8G8B8A8_SRGB), (normal, B.FORMAT_R8G8B8A8_UNORM), (mr, B.FORMAT_R8G8B8A8_UNORM),
-                     (ao, B.FORMAT_R8G8B8A8_UNORM), (em, B.FORMAT_R8G8B8A8_UNORM)):
-        ids.append(r.make_texture(r.load_image(img, fmt)))
-    return ids
+    return albedo, normal, mr, ao, em
 
 
 def make_material(tex=None, base_color=(1, 1, 1, 1), emissive=(0, 0, 0), metallic=1.0, roughness=1.0, ao=1.0,
