@@ -13,7 +13,8 @@ import numpy as np
 from . import _binding as B
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "lib", "librdr_hip.so")
+# RDR_HIP_LIB selects another build of the same library (A/B experiments); there is still no non-HIP path
+HIP_LIB_PATH = os.environ.get("RDR_HIP_LIB") or os.path.join(_HERE, "lib", "librdr_hip.so")
 
 
 class RendererError(RuntimeError):

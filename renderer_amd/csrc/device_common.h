@@ -70,10 +70,11 @@ template <int MB> RDR_DEV uint32_t float_to_ufloat(float f) {
     return (m | 0x800000u) >> shift;
 }
 template <int MB> RDR_DEV float ufloat_to_float(uint32_t v) {
-    const uint32_t e = v >> MB, m = v & ((1u << MB) - 1u);
-    if (e == 0) return (float)m * __uint_as_float((uint32_t)(127 - 14 - MB) << 23);
-    if (e == 31) return __uint_as_float(0x7F800000u | (m << (23 - MB)));
-    return __uint_as_float(((e + 112u) << 23) | (m << (23 - MB)));
+    // normal numbers: re-bias the exponent by 127 - 15; Inf/NaN (e == 31) need 255 instead of 143
+    uint32_t bits = (v << (23 - MB)) + (112u << 23);
+    if (v >= (31u << MB)) bits += 112u << 23;
+    const float den = (float)v * __uint_as_float((uint32_t)(127 - 14 - MB) << 23);  // e == 0: v is the mantissa
+    return v < (1u << MB) ? den : __uint_as_float(bits);
 }
 RDR_DEV uint32_t pack_r11g11b10(float r, float g, float b) {
     return float_to_ufloat<6>(r) | (float_to_ufloat<6>(g) << 11) | (float_to_ufloat<5>(b) << 22);
@@ -128,8 +129,13 @@ RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, 
 }
 
 // ---- 2D material textures: trilinear, isotropic LOD
+#define RDR_INV255 (1.0f / 255.0f)
+
 RDR_DEV int wrap_index(int i, int n, uint32_t mode) {
-    if (mode == 0u) { int r = i % n; return r < 0 ? r + n : r; }
+    if (mode == 0u) {
+        if ((n & (n - 1)) == 0) return i & (n - 1);  // power-of-two size: two's complement AND is the floor modulo
+        int r = i % n; return r < 0 ? r + n : r;
+    }
     if (mode == 1u) {
         const int period = 2 * n;
         int r = i % period; if (r < 0) r += period;
@@ -137,7 +143,9 @@ RDR_DEV int wrap_index(int i, int n, uint32_t mode) {
     }
     return min(max(i, 0), n - 1);
 }
-RDR_DEV void tex_bilinear(const DFrame& fr, const DTexture& t, uint32_t level, float u, float v, float out[4]) {
+// `srgb` points at the 256-entry sRGB decode table (LDS copy in the hot kernels).
+// UNORM channels decode as byte * (1/255).
+RDR_DEV void tex_bilinear(const float* srgb, const DTexture& t, uint32_t level, float u, float v, float out[4]) {
     const uint32_t ww = t.w >> level, hh = t.h >> level;
     const int w = (int)(ww ? ww : 1u), h = (int)(hh ? hh : 1u);
     const uint32_t* px = (const uint32_t*)t.base + t.level_offset[level];
@@ -148,31 +156,32 @@ RDR_DEV void tex_bilinear(const DFrame& fr, const DTexture& t, uint32_t level, f
     const int i0 = wrap_index((int)fu, w, wu), i1 = wrap_index((int)fu + 1, w, wu);
     const int j0 = wrap_index((int)fv, h, wv), j1 = wrap_index((int)fv + 1, h, wv);
     const uint32_t q00 = px[j0 * w + i0], q10 = px[j0 * w + i1], q01 = px[j1 * w + i0], q11 = px[j1 * w + i1];
-    const float* rgb = (t.flags & 1u) ? fr.srgb_decode : fr.unorm_decode;
+    const bool is_srgb = (t.flags & 1u) != 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float* tab = k < 3 ? rgb : fr.unorm_decode;
-        const float t00 = tab[(q00 >> (8 * k)) & 255u], t10 = tab[(q10 >> (8 * k)) & 255u];
-        const float t01 = tab[(q01 >> (8 * k)) & 255u], t11 = tab[(q11 >> (8 * k)) & 255u];
+        const uint32_t b00 = (q00 >> (8 * k)) & 255u, b10 = (q10 >> (8 * k)) & 255u, b01 = (q01 >> (8 * k)) & 255u, b11 = (q11 >> (8 * k)) & 255u;
+        float t00, t10, t01, t11;
+        if (k < 3 && is_srgb) { t00 = srgb[b00]; t10 = srgb[b10]; t01 = srgb[b01]; t11 = srgb[b11]; }
+        else { t00 = (float)b00 * RDR_INV255; t10 = (float)b10 * RDR_INV255; t01 = (float)b01 * RDR_INV255; t11 = (float)b11 * RDR_INV255; }
         const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
         out[k] = (1.0f - b) * top + b * bot;
     }
 }
-RDR_DEV void tex_sample(const DFrame& fr, uint32_t tex, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4]) {
-    const DTexture& t = fr.textures[tex];
+// texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2)
+RDR_DEV void tex_sample(const float* srgb, const DTexture& t, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4]) {
     float lambda = 0.0f;
     if (t.levels > 1u) {
         const float ax = dudx * (float)t.w, ay = dvdx * (float)t.h, bx = dudy * (float)t.w, by = dvdy * (float)t.h;
-        const float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
-        if (rho > 1.0f) lambda = fminf(__log2f(rho), (float)(t.levels - 1u));
+        const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+        if (rho2 > 1.0f) lambda = fminf(0.5f * __log2f(rho2), (float)(t.levels - 1u));
     }
-    if (!(lambda > 0.0f)) { tex_bilinear(fr, t, 0, u, v, out); return; }
+    if (!(lambda > 0.0f)) { tex_bilinear(srgb, t, 0, u, v, out); return; }
     const float fl = floorf(lambda);
     const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, t.levels - 1u);
     const float f = lambda - fl;
     float c0[4], c1[4];
-    tex_bilinear(fr, t, l0, u, v, c0);
-    tex_bilinear(fr, t, l1, u, v, c1);
+    tex_bilinear(srgb, t, l0, u, v, c0);
+    tex_bilinear(srgb, t, l1, u, v, c1);
 #pragma unroll
     for (int k = 0; k < 4; k++) out[k] = (1.0f - f) * c0[k] + f * c1[k];
 }

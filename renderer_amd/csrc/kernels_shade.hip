@@ -105,7 +105,18 @@ RDR_DEV void shade_sky(const DFrame& fr, int px, int py, float out[4]) {
 }
 
 // basic.vert for the triangle's three vertices + pbr.frag at the centre of pixel (px,py)
-__device__ __noinline__ void shade_fragment(const DFrame& fr, const DDraw& d, uint32_t tri, int px, int py, float out[4]) {
+#ifndef RDR_SHADE_INLINE
+#define RDR_SHADE_INLINE 0
+#endif
+#ifndef RDR_SHADE_WAVES
+#define RDR_SHADE_WAVES 1
+#endif
+#if RDR_SHADE_INLINE
+__device__ __forceinline__ void shade_fragment(
+#else
+__device__ __noinline__ void shade_fragment(
+#endif
+const DFrame& fr, const float* srgb, const DDraw& d, uint32_t tri, int px, int py, float out[4]) {
     const DPrim& pr = fr.prims[d.prim];
     const uint32_t* ip = fr.idx + pr.first_index + 3u * tri;
     const uint32_t vi[3] = {pr.first_vertex + ip[0], pr.first_vertex + ip[1], pr.first_vertex + ip[2]};
@@ -161,17 +172,17 @@ __device__ __noinline__ void shade_fragment(const DFrame& fr, const DDraw& d, ui
 
     // ---- pbr.frag main()
     float t[4];
-    tex_sample(fr, mt.tex[0] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[0], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample(srgb, fr.textures[mt.tex[0] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[0]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float albedo[4] = {t[0] * mt.base_color[0], t[1] * mt.base_color[1], t[2] * mt.base_color[2], t[3] * mt.base_color[3]};
     if (mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
-    tex_sample(fr, mt.tex[2] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[2], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample(srgb, fr.textures[mt.tex[2] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[2]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
     const float roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
-    tex_sample(fr, mt.tex[3] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[3], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample(srgb, fr.textures[mt.tex[3] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[3]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float ao = t[0] * mt.ao;
-    tex_sample(fr, mt.tex[4] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[4], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample(srgb, fr.textures[mt.tex[4] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[4]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float emissive[3] = {t[0] * mt.emissive[0], t[1] * mt.emissive[1], t[2] * mt.emissive[2]};
-    tex_sample(fr, mt.tex[1] == 0xFFFFFFFFu ? fr.tex_normal : mt.tex[1], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample(srgb, fr.textures[mt.tex[1] == 0xFFFFFFFFu ? fr.tex_normal : mt.tex[1]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
     const float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f, nz = t[2] * 2.0f - 1.0f;
     const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
@@ -244,8 +255,8 @@ __device__ __noinline__ void shade_fragment(const DFrame& fr, const DDraw& d, ui
             const uint32_t q00 = lp[j0 * w + i0], q10 = lp[j0 * w + i1], q01 = lp[j1 * w + i0], q11 = lp[j1 * w + i1];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const float t00 = fr.unorm_decode[(q00 >> (8 * k)) & 255u], t10 = fr.unorm_decode[(q10 >> (8 * k)) & 255u];
-                const float t01 = fr.unorm_decode[(q01 >> (8 * k)) & 255u], t11 = fr.unorm_decode[(q11 >> (8 * k)) & 255u];
+                const float t00 = (float)((q00 >> (8 * k)) & 255u) * RDR_INV255, t10 = (float)((q10 >> (8 * k)) & 255u) * RDR_INV255;
+                const float t01 = (float)((q01 >> (8 * k)) & 255u) * RDR_INV255, t11 = (float)((q11 >> (8 * k)) & 255u) * RDR_INV255;
                 const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
                 lut[k] = (1.0f - b) * top + b * bot;
             }
@@ -282,11 +293,14 @@ RDR_DEV uint32_t find_draw_by_tri(const uint32_t* __restrict__ first_tri, uint32
 // colours when `samples_out` is given (a blended pass follows), else resolves
 // straight into hdr.
 template <int S>
-__global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__ frp, const DDraw* __restrict__ draws,
+__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFrame* __restrict__ frp, const DDraw* __restrict__ draws,
                                                       const uint32_t* __restrict__ first_tri, uint32_t n_draws,
                                                       const float* __restrict__ depth, const uint32_t* __restrict__ vis,
                                                       uint2* __restrict__ hdr, uint2* __restrict__ samples_out) {
+    __shared__ float lds_srgb[256];
     const DFrame& fr = *frp;
+    lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
+    __syncthreads();
     const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
     const int tx = (int)(blockIdx.x % tiles_x), ty = (int)(blockIdx.x / tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -312,7 +326,7 @@ __global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__
             for (; u < n_unique; u++) if (ids[u] == id) break;
             if (u == n_unique) {
                 const uint32_t di = find_draw_by_tri(first_tri, n_draws, id);
-                shade_fragment(fr, draws[di], id - first_tri[di], px, py, cols[u]);
+                shade_fragment(fr, lds_srgb, draws[di], id - first_tri[di], px, py, cols[u]);
                 ids[u] = id;
                 n_unique++;
             }
@@ -363,7 +377,9 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
                                                       const uint32_t* __restrict__ tile_end, uint2* __restrict__ color) {
     __shared__ uint32_t lds_rec[BLEND_CHUNK * 32];
     __shared__ uint32_t lds_ids[BLEND_CHUNK];
+    __shared__ float lds_srgb[256];
     const DFrame& fr = *frp;
+    lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
     const DView vw = views[0];
     const uint32_t tile = blockIdx.x;
     const uint32_t begin = tile_start[tile], end = tile_end[tile];
@@ -425,7 +441,7 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
                 const uint32_t rid = r->id;
                 const uint32_t di = find_draw_by_tri(first_tri, n_draws, rid);
                 float src[4];
-                shade_fragment(fr, draws[di], rid - first_tri[di], px, py, src);
+                shade_fragment(fr, lds_srgb, draws[di], rid - first_tri[di], px, py, src);
                 const float a = src[3];
 #pragma unroll
                 for (int s = 0; s < S; s++)
