@@ -1,0 +1,139 @@
+"""Frame-batch sharding across the GPUs of one node.
+
+Frames (and camera views) are independent units of the per-frame pipeline: the
+scene is replicated on every GPU, frame k of a job goes to rank k mod R, and
+the only exchange is the gather of the finished RGBA8 images to rank 0. One
+process per GPU, `torch.distributed` with the "nccl" backend (RCCL over xGMI);
+the same code runs with "gloo" and host tensors, which is how it is tested
+without GPUs.
+
+The gather of frame k is issued asynchronously and waited for only when its
+staging slot is needed again, so it overlaps the rendering of the next frames.
+Rank 0 receives over up to R-1 distinct xGMI links at once (a 4K RGBA8 frame is
+33 MB, about 0.2 ms per link), which is why a plain gather is used rather than
+a ring all-gather.
+
+The reference renders on one device only (one vk::Queue,
+Renderer/VulkanRenderer.cpp:548); this module has no counterpart there.
+"""
+import numpy as np
+
+
+def frames_of_rank(n_frames, rank, world):
+    """Frame indices rendered by `rank`: k with k mod world == rank, in order."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return list(range(rank, int(n_frames), world))
+
+
+def rounds(n_frames, world):
+    """Number of gather rounds: every rank takes part in each of them (ranks without a frame send padding)."""
+    return (int(n_frames) + world - 1) // world
+
+
+class FrameSharder:
+    """Renders this rank's share of a frame batch and gathers the images to rank 0.
+
+    renderer  : api.Renderer bound to this rank's GPU
+    dist      : the initialised torch.distributed module, or None for a single process
+    device    : torch device of the staging tensors ("cuda:N" with nccl, "cpu" with gloo)
+    depth     : staging slots; depth-1 gathers can be in flight while a frame renders
+    """
+
+    def __init__(self, renderer, dist=None, device="cpu", depth=2):
+        import torch
+        self.torch = torch
+        self.r = renderer
+        self.dist = dist
+        self.rank = dist.get_rank() if dist else 0
+        self.world = dist.get_world_size() if dist else 1
+        self.device = torch.device(device)
+        self.depth = max(1, int(depth))
+        H, W = renderer.height, renderer.width
+        self.slots = [torch.empty((H, W, 4), dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+        self.recv = None
+        if dist and self.rank == 0:
+            self.recv = [[torch.empty((H, W, 4), dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+                         for _ in range(self.depth)]
+        self.pending = [None] * self.depth   # (work handle, round index) per slot
+        self.luminance = {}
+
+    # -- one frame ---------------------------------------------------------
+    def _render_into(self, tensor, frame_params):
+        if tensor.is_cuda:
+            self.r.render_frame(device_ptr=tensor.data_ptr(), **frame_params)
+            self.r.synchronize()
+            return self.r.frame_stats().avg_log_luminance
+        out = tensor.numpy()
+        _, avg = self.r.render_frame(out=out, **frame_params)
+        return avg
+
+    def _retire(self, slot, on_frames):
+        if self.pending[slot] is None:
+            return
+        work, rnd, n_valid = self.pending[slot]
+        if work is not None:
+            work.wait()
+        self.pending[slot] = None
+        if on_frames is not None and self.rank == 0:
+            imgs = self.recv[slot] if self.recv is not None else [self.slots[slot]]
+            for src in range(n_valid):
+                on_frames(rnd * self.world + src, imgs[src])
+
+    def run(self, n_frames, set_frame, frame_params=None, on_frame=None):
+        """Renders frames 0..n_frames-1 of the job. `set_frame(renderer, k)` positions the camera / nodes for
+        frame k. On rank 0 `on_frame(k, image_tensor)` is called once per frame, in increasing k, with the
+        gathered image (valid only during the call). Returns {frame index: avg log-luminance} of this rank."""
+        frame_params = dict(frame_params or {})
+        n_rounds = rounds(n_frames, self.world)
+        for rnd in range(n_rounds):
+            slot = rnd % self.depth
+            self._retire(slot, on_frame)
+            k = rnd * self.world + self.rank
+            if k < n_frames:
+                set_frame(self.r, k)
+                self.luminance[k] = self._render_into(self.slots[slot], frame_params)
+            n_valid = min(self.world, n_frames - rnd * self.world)
+            work = None
+            if self.dist:
+                work = self.dist.gather(self.slots[slot], self.recv[slot] if self.rank == 0 else None, dst=0, async_op=True)
+            self.pending[slot] = (work, rnd, n_valid)
+        # drain in round order
+        order = sorted((p[1], s) for s, p in enumerate(self.pending) if p is not None)
+        for _, s in order:
+            self._retire(s, on_frame)
+        return dict(self.luminance)
+
+    def gather_luminance(self, n_frames):
+        """All ranks get the avg log-luminance of every frame of the job (one float per frame), the exchange the
+        exposure recurrence needs when frames of one sequence are rendered on different GPUs."""
+        torch = self.torch
+        n_rounds = rounds(n_frames, self.world)
+        mine = torch.zeros(n_rounds, dtype=torch.float32, device=self.device)
+        for k, v in self.luminance.items():
+            mine[k // self.world] = float(v)
+        if not self.dist:
+            return mine.cpu().numpy()[:n_frames].copy()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        table = torch.stack(parts, 1).reshape(-1).cpu().numpy()  # [round][rank] -> frame index
+        return table[:n_frames].copy()
+
+
+def exposure_sequence(avg_log_luminance, delta_time, exposure_bias=0.0, start=0.0):
+    """The reference's exposure recurrence over a frame sequence (Renderer/VulkanRenderer.cpp:1075-1082), as a
+    function of the per-frame average log-luminance. Frame k uses the luminance of frame k-1 (0 for the first).
+    Returns (temporal_luminance[k], exposure[k]) as float32 arrays."""
+    n = len(avg_log_luminance)
+    tl = np.zeros(n, np.float32)
+    ex = np.zeros(n, np.float32)
+    cur = np.float32(start)
+    prev = np.float32(0.0)
+    for k in range(n):
+        avg = min(prev, np.float32(10.0))
+        cur = np.float32(float(cur) + (float(np.exp2(np.float32(avg))) - float(cur)) * (1.0 - np.exp(-float(delta_time))))
+        tl[k] = cur
+        e = np.float32(1.03) - np.float32(2.0) / (np.log2(np.float32(cur + np.float32(1.0))) + np.float32(2.0))
+        ex[k] = np.float32(0.18) / np.float32(e) + np.float32(exposure_bias)
+        prev = np.float32(avg_log_luminance[k])
+    return tl, ex

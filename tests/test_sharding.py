@@ -1,0 +1,105 @@
+"""Frame-batch sharding (renderer_amd/sharding.py) with two processes over gloo, on the CPU.
+
+The ranks drive the CPU checker library through the same C ABI the HIP library exports, so the partition,
+the asynchronous gather with staging-slot reuse, the padding of the last round and the luminance exchange are
+exercised exactly as bench.py uses them with nccl (RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from renderer_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, N_FRAMES = 64, 36, 5
+
+
+def _set_frame(r, k):
+    r.set_camera(position=(0.4 + 0.3 * k, 1.7, 5.2 - 0.2 * k), euler=(-0.2, 0.05 + 0.04 * k, 0.0))
+
+
+def _make_renderer():
+    from oracle import orc
+    from renderer_amd import scenes
+    from renderer_amd.api import Renderer, default_settings
+    r = Renderer(orc.capi(), W, H, default_settings(msaa=1, directional_shadow_map_resolution=128, point_shadow_map_resolution=32))
+    scenes.small_scene(r, tex_size=16, env_res=8)
+    return r
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        r = _make_renderer()
+        sh = sharding.FrameSharder(r, dist=dist, device="cpu", depth=2)
+        got = {}
+
+        def on_frame(k, img):
+            assert k not in got
+            got[k] = img.numpy().copy()
+
+        lum = sh.run(N_FRAMES, _set_frame, dict(exposure_mode=1, temporal_luminance=0.5), on_frame)
+        assert sorted(lum) == sharding.frames_of_rank(N_FRAMES, rank, world)
+        table = sh.gather_luminance(N_FRAMES)
+        np.save(os.path.join(out_dir, f"lum_{rank}.npy"), table)
+        if rank == 0:
+            assert sorted(got) == list(range(N_FRAMES))
+            np.save(os.path.join(out_dir, "frames.npy"), np.stack([got[k] for k in range(N_FRAMES)]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_partition():
+    assert sharding.frames_of_rank(10, 1, 4) == [1, 5, 9]
+    assert sharding.frames_of_rank(3, 3, 4) == []
+    assert sharding.rounds(10, 4) == 3 and sharding.rounds(8, 4) == 2 and sharding.rounds(0, 4) == 0
+    allk = sorted(k for rk in range(8) for k in sharding.frames_of_rank(256, rk, 8))
+    assert allk == list(range(256))
+    assert all(len(sharding.frames_of_rank(256, rk, 8)) == 32 for rk in range(8))
+    with pytest.raises(ValueError):
+        sharding.frames_of_rank(4, 4, 4)
+
+
+def test_two_rank_gloo_gather_matches_serial(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    frames = np.load(tmp_path / "frames.npy")
+    # serial rendering of the same job in this process
+    r = _make_renderer()
+    sh = sharding.FrameSharder(r, dist=None, device="cpu", depth=2)
+    serial = {}
+    lum = sh.run(N_FRAMES, _set_frame, dict(exposure_mode=1, temporal_luminance=0.5), lambda k, img: serial.__setitem__(k, img.numpy().copy()))
+    assert sorted(serial) == list(range(N_FRAMES))
+    for k in range(N_FRAMES):
+        assert np.array_equal(frames[k], serial[k]), f"frame {k} differs between the 2-rank and the serial run"
+    assert len({frames[k].tobytes() for k in range(N_FRAMES)}) == N_FRAMES, "frames must differ from each other"
+    t0, t1 = np.load(tmp_path / "lum_0.npy"), np.load(tmp_path / "lum_1.npy")
+    assert np.array_equal(t0, t1)
+    assert np.allclose(t0, [lum[k] for k in range(N_FRAMES)], atol=0)
+
+
+def test_exposure_sequence_follows_the_reference_recurrence():
+    """VulkanRenderer.cpp:1079-1082 by hand for two frames at dt = 1/30."""
+    avg = [1.0, 2.0, 0.5]
+    tl, ex = sharding.exposure_sequence(avg, 1.0 / 30.0)
+    g = 1.0 - np.exp(-1.0 / 30.0)
+    t0 = 0.0 + (2.0 ** 0.0 - 0.0) * g          # first frame sees luminance 0 -> 2^0
+    t1 = t0 + (2.0 ** 1.0 - t0) * g
+    t2 = t1 + (2.0 ** 2.0 - t1) * g
+    assert np.allclose(tl, [t0, t1, t2], rtol=1e-6)
+    assert np.allclose(ex, [0.18 / (1.03 - 2.0 / (np.log2(t + 1.0) + 2.0)) for t in (t0, t1, t2)], rtol=1e-5)
