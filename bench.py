@@ -79,45 +79,28 @@ def main():
     build_s = time.time() - t0
     n_lights = 16
 
-    # finished frames stay on the device; two buffers so that the gather of frame k overlaps frame k+1
-    bufs = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    gather_lists = [[torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(world)] for _ in range(2)] if (dist and rank == 0) else [None, None]
-    pending = [None, None]
+    # finished frames stay on the device; two staging slots so that the gather of frame k overlaps frame k+1
+    from renderer_amd.sharding import FrameSharder
+    sharder = FrameSharder(r, dist=dist, device=f"cuda:{local_rank}", depth=2)
+    frame_params = dict(exposure_mode=1, temporal_luminance=0.5)
+    acc = {"shade_kernel": 0.0, "raster_kernel": 0.0, "geometry": 0.0, "shade": 0.0, "bloom": 0.0, "tonemap": 0.0, "total": 0.0}
+    last_stats = [None]
 
-    def step(k):
-        slot = k & 1
-        if pending[slot] is not None:
-            pending[slot].wait()
-            pending[slot] = None
-        camera_for_frame(r, k * world + rank)
-        r.render_frame(exposure_mode=1, temporal_luminance=0.5, device_ptr=bufs[slot].data_ptr())
-        r.synchronize()
-        if dist:
-            pending[slot] = dist.gather(bufs[slot], gather_lists[slot], dst=0, async_op=True)
+    def after_render(_k):
+        s = r.frame_stats()
+        last_stats[0] = s
+        acc["shade_kernel"] += s.ms_shade_kernel; acc["raster_kernel"] += s.ms_raster_kernel; acc["geometry"] += s.ms_geometry
+        acc["shade"] += s.ms_shade; acc["bloom"] += s.ms_bloom; acc["tonemap"] += s.ms_tonemap; acc["total"] += s.ms_total
 
-    def drain():
-        for s in range(2):
-            if pending[s] is not None:
-                pending[s].wait()
-                pending[s] = None
-        torch.cuda.synchronize()
-
-    for k in range(a.warmup):
-        step(k)
-    drain()
+    # every rank renders `warmup` then `steps` frames of the camera path: frame k of the job goes to rank k mod world
+    sharder.run(a.warmup * world, camera_for_frame, frame_params)
+    torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    acc = {"shade_kernel": 0.0, "raster_kernel": 0.0, "geometry": 0.0, "shade": 0.0, "bloom": 0.0, "tonemap": 0.0, "total": 0.0}
-    last_stats = None
     t_start = time.perf_counter()
-    for k in range(a.steps):
-        step(a.warmup + k)
-        s = r.frame_stats()
-        last_stats = s
-        acc["shade_kernel"] += s.ms_shade_kernel; acc["raster_kernel"] += s.ms_raster_kernel; acc["geometry"] += s.ms_geometry
-        acc["shade"] += s.ms_shade; acc["bloom"] += s.ms_bloom; acc["tonemap"] += s.ms_tonemap; acc["total"] += s.ms_total
-    drain()
+    sharder.run(a.steps * world, lambda rr, k: camera_for_frame(rr, a.warmup * world + k), frame_params, after_render=after_render)
+    torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -126,6 +109,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    last_stats = last_stats[0]
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

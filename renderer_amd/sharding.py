@@ -80,10 +80,12 @@ class FrameSharder:
             for src in range(n_valid):
                 on_frames(rnd * self.world + src, imgs[src])
 
-    def run(self, n_frames, set_frame, frame_params=None, on_frame=None):
+    def run(self, n_frames, set_frame, frame_params=None, on_frame=None, after_render=None):
         """Renders frames 0..n_frames-1 of the job. `set_frame(renderer, k)` positions the camera / nodes for
         frame k. On rank 0 `on_frame(k, image_tensor)` is called once per frame, in increasing k, with the
-        gathered image (valid only during the call). Returns {frame index: avg log-luminance} of this rank."""
+        gathered image (valid only during the call). `after_render(k)` runs on the rendering rank right after
+        frame k has finished on its GPU (per-frame statistics). Returns {frame index: avg log-luminance} of
+        this rank."""
         frame_params = dict(frame_params or {})
         n_rounds = rounds(n_frames, self.world)
         for rnd in range(n_rounds):
@@ -93,6 +95,8 @@ class FrameSharder:
             if k < n_frames:
                 set_frame(self.r, k)
                 self.luminance[k] = self._render_into(self.slots[slot], frame_params)
+                if after_render is not None:
+                    after_render(k)
             n_valid = min(self.world, n_frames - rnd * self.world)
             work = None
             if self.dist:
