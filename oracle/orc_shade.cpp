@@ -169,8 +169,8 @@ static void shade_fragment(const ShadeCtx& sc, const Draw& d, uint32_t tri, int 
         const double xn = e == 1 ? xs[1] : xs[0], yn = e == 2 ? ys[2] : ys[0];
         double l[3];
         for (int k = 0; k < 3; k++) l[k] = std::fma(A[k], xn, std::fma(B[k], yn, C[k]));
-        const double sum = (l[0] + l[1]) + l[2];
-        for (int k = 0; k < 3; k++) lam[e][k] = (float)(l[k] / sum);
+        const double inv = 1.0 / ((l[0] + l[1]) + l[2]);
+        for (int k = 0; k < 3; k++) lam[e][k] = (float)(l[k] * inv);
     }
 
     // ---- vertex shader outputs
@@ -226,18 +226,22 @@ static void shade_fragment(const ShadeCtx& sc, const Draw& d, uint32_t tri, int 
                 0.04f * (1.0f - metallic) + alb.z * metallic};
     V3 Lo{0, 0, 0};
 
-    // point lights (pbr.frag:123-160)
+    // point lights (pbr.frag:123-160). Two expressions are restated in an algebraically equal form so that the
+    // discontinuous tests need one correctly rounded divide instead of a sqrt and five divides:
+    //   radiance = I / distance^2 with distance^2 = dot(Lv, Lv); "max(radiance) <= 1e-3" is tested as
+    //   max(I) <= 1e-3 * distance^2;
+    //   (far - far*near/d) / (far - near) = c0 - c1/d with c0 = far/(far-near), c1 = far*near/(far-near).
     const float far = 100.0f, near = 0.1f;
+    const float c0 = far / (far - near), c1 = (far * near) / (far - near);
     for (const PointLight& pl : c.lights) {
         const V3 Lv = pl.point - P;
-        const float dist = std::sqrt(dot(Lv, Lv));  // distance(lightPos, worldPos)
-        const float attenuation = 1.0f / (dist * dist);
-        const V3 radiance = pl.intensity * attenuation;
-        if (std::max(radiance.x, std::max(radiance.y, radiance.z)) <= 1e-3f) continue;
-        float lightDepth = std::max(std::fabs(Lv.x), std::max(std::fabs(Lv.y), std::fabs(Lv.z))) - 0.05f;
-        lightDepth = (far - far * near / lightDepth) / (far - near);
+        const float d2 = dot(Lv, Lv);
+        if (std::max(pl.intensity.x, std::max(pl.intensity.y, pl.intensity.z)) <= 1e-3f * d2) continue;
+        const V3 radiance = pl.intensity * (1.0f / d2);
         const bool castShadow = pl.flags & RDR_POINT_LIGHT_CAST_SHADOWS, hasShadowMap = pl.flags & RDR_POINT_LIGHT_HAS_SHADOW_MAP;
         if (castShadow && hasShadowMap) {
+            float lightDepth = std::max(std::fabs(Lv.x), std::max(std::fabs(Lv.y), std::fabs(Lv.z))) - 0.05f;
+            lightDepth = c0 - c1 / lightDepth;
             const float shadowTest = shadow_cube(c, pl.shadow_map_index, -Lv.x, -Lv.y, -Lv.z, lightDepth);
             if (shadowTest < 1e-3f) continue;
             const V3 r = BRDF(radiance, normalize(Lv), N, V, alb, roughness, metallic, F0);

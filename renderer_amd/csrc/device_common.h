@@ -128,6 +128,43 @@ RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, 
     }
 }
 
+// Variants for shading, where the result is continuous in the direction: the
+// face coordinates use the hardware reciprocal instead of two IEEE divides.
+RDR_DEV int cube_face_fast(float rx, float ry, float rz, float& s, float& t) {
+    const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+    int face; float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = rz < 0.0f ? 5 : 4; sc = rz < 0.0f ? -rx : rx; tc = -ry; ma = az; }
+    else if (ay >= ax) { face = ry < 0.0f ? 3 : 2; sc = rx; tc = ry < 0.0f ? -rz : rz; ma = ay; }
+    else { face = rx < 0.0f ? 1 : 0; sc = rx < 0.0f ? rz : -rz; tc = -ry; ma = ax; }
+    const float hinv = 0.5f * __builtin_amdgcn_rcpf(ma);
+    s = fmaf(sc, hinv, 0.5f);
+    t = fmaf(tc, hinv, 0.5f);
+    return face;
+}
+RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
+    float s, t;
+    const int face = cube_face_fast(dx, dy, dz, s, t);
+    const uint32_t rr = cube.res >> level;
+    const int r = (int)(rr ? rr : 1u);
+    const uint32_t* px = cube.texels + cube.level_offset[level] + (size_t)face * r * r;
+    const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = min(max((int)fu, 0), r - 1), i1 = min(max((int)fu + 1, 0), r - 1);
+    const int j0 = min(max((int)fv, 0), r - 1), j1 = min(max((int)fv + 1, 0), r - 1);
+    const uint32_t q00 = px[j0 * r + i0], q10 = px[j0 * r + i1], q01 = px[j1 * r + i0], q11 = px[j1 * r + i1];
+    float c00[3], c10[3], c01[3], c11[3];
+    unpack_r11g11b10(q00, c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(q10, c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(q01, c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(q11, c11[0], c11[1], c11[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float top = fmaf(a, c10[k] - c00[k], c00[k]), bot = fmaf(a, c11[k] - c01[k], c01[k]);
+        out[k] = fmaf(b, bot - top, top);
+    }
+}
+
 // ---- 2D material textures: trilinear, isotropic LOD
 #define RDR_INV255 (1.0f / 255.0f)
 
@@ -144,7 +181,9 @@ RDR_DEV int wrap_index(int i, int n, uint32_t mode) {
     return min(max(i, 0), n - 1);
 }
 // `srgb` points at the 256-entry sRGB decode table (LDS copy in the hot kernels).
-// UNORM channels decode as byte * (1/255).
+// UNORM channels decode as byte * (1/255). MASK selects the channels the caller
+// reads (bit k = channel k); the others are left untouched.
+template <int MASK>
 RDR_DEV void tex_bilinear(const float* srgb, const DTexture& t, uint32_t level, float u, float v, float out[4]) {
     const uint32_t ww = t.w >> level, hh = t.h >> level;
     const int w = (int)(ww ? ww : 1u), h = (int)(hh ? hh : 1u);
@@ -159,15 +198,17 @@ RDR_DEV void tex_bilinear(const float* srgb, const DTexture& t, uint32_t level, 
     const bool is_srgb = (t.flags & 1u) != 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+        if (!(MASK & (1 << k))) continue;
         const uint32_t b00 = (q00 >> (8 * k)) & 255u, b10 = (q10 >> (8 * k)) & 255u, b01 = (q01 >> (8 * k)) & 255u, b11 = (q11 >> (8 * k)) & 255u;
         float t00, t10, t01, t11;
         if (k < 3 && is_srgb) { t00 = srgb[b00]; t10 = srgb[b10]; t01 = srgb[b01]; t11 = srgb[b11]; }
         else { t00 = (float)b00 * RDR_INV255; t10 = (float)b10 * RDR_INV255; t01 = (float)b01 * RDR_INV255; t11 = (float)b11 * RDR_INV255; }
-        const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
-        out[k] = (1.0f - b) * top + b * bot;
+        const float top = fmaf(a, t10 - t00, t00), bot = fmaf(a, t11 - t01, t01);
+        out[k] = fmaf(b, bot - top, top);
     }
 }
 // texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2)
+template <int MASK>
 RDR_DEV void tex_sample(const float* srgb, const DTexture& t, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4]) {
     float lambda = 0.0f;
     if (t.levels > 1u) {
@@ -175,13 +216,14 @@ RDR_DEV void tex_sample(const float* srgb, const DTexture& t, float u, float v, 
         const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
         if (rho2 > 1.0f) lambda = fminf(0.5f * __log2f(rho2), (float)(t.levels - 1u));
     }
-    if (!(lambda > 0.0f)) { tex_bilinear(srgb, t, 0, u, v, out); return; }
+    if (!(lambda > 0.0f)) { tex_bilinear<MASK>(srgb, t, 0, u, v, out); return; }
     const float fl = floorf(lambda);
     const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, t.levels - 1u);
     const float f = lambda - fl;
     float c0[4], c1[4];
-    tex_bilinear(srgb, t, l0, u, v, c0);
-    tex_bilinear(srgb, t, l1, u, v, c1);
+    tex_bilinear<MASK>(srgb, t, l0, u, v, c0);
+    tex_bilinear<MASK>(srgb, t, l1, u, v, c1);
 #pragma unroll
-    for (int k = 0; k < 4; k++) out[k] = (1.0f - f) * c0[k] + f * c1[k];
+    for (int k = 0; k < 4; k++)
+        if (MASK & (1 << k)) out[k] = fmaf(f, c1[k] - c0[k], c0[k]);
 }

@@ -6,16 +6,27 @@
 // env.frag:10-17; pass order and blend state Renderer/VulkanRenderer.cpp:1043-1065,
 // :862-866.
 //
-// Layout: one thread per pixel, 256-thread blocks covering the same 16x16
-// tiles (8x8 per wave) as the rasteriser, so a wave's pixels share triangles,
-// materials and texture footprints. All scene data is read in place from HBM
-// (geometry arena, RGBA8 mip chains, packed-float cubes, D32F shadow arrays).
+// Structure of the opaque pass (k_shade_setup -> k_shade_opaque):
+//  * k_shade_setup, one thread per main-view triangle that survived set-up:
+//    runs basic.vert for its three vertices once and stores the outputs plus
+//    the perspective-correct barycentric planes in a 256-byte DShadeTri, so a
+//    fragment never re-transforms vertices.
+//  * k_shade_opaque, one 256-thread block per 16x16 tile. With 4x MSAA a pixel
+//    is shaded once per DISTINCT triangle among its samples; looping over
+//    those inside the pixel's lane leaves most lanes idle on the 2nd..4th
+//    pass. Instead the block compacts its (pixel, triangle) fragments into a
+//    list in LDS (ballot prefix sums), shades the list densely - every lane a
+//    fragment - parks the RGBA16F results in LDS, and each pixel then
+//    resolves its samples from there.
+// All scene data is read in place from HBM (geometry arena, RGBA8 mip chains,
+// packed-float cubes, D32F shadow arrays).
 //
 // Values that feed a discontinuous decision (shadow compares, cascade choice,
 // light cut-offs) are computed with correctly rounded operations in a fixed
 // order: barycentrics in double, world position and light-space coordinates
-// with explicit fma chains. The continuous BRDF math below them may use the
-// fast reciprocal / rsqrt / contraction.
+// with explicit fma chains, the shadow reference depth with an IEEE divide.
+// Everything downstream of those is continuous in its inputs (bilinear PCF
+// weights, filtered colours, the BRDF) and may use rcp / rsq / contraction.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -45,7 +56,7 @@ RDR_DEV float shadow_pcf(const float* __restrict__ map, int res, float s, float 
 RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, float rz, float ref) {
     const int res = (int)fr.point_res;
     float s, t;
-    const int face = cube_face(rx, ry, rz, s, t);
+    const int face = cube_face_fast(rx, ry, rz, s, t);  // the PCF result is continuous in (s,t)
     const float* map = fr.point_shadow + ((size_t)slot * 6 + face) * res * res;
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
@@ -95,7 +106,7 @@ RDR_DEV void shade_sky(const DFrame& fr, int px, int py, float out[4]) {
     pos.z = fmaf(m[2], xn, fmaf(m[6], yn, m[10] + m[14]));
     const F3 d = normalize3(pos);
     float e[3] = {0.0f, 0.0f, 0.0f};
-    if (fr.env.res) cube_sample(fr.env, 0, d.x, d.y, d.z, e);
+    if (fr.env.res) cube_sample_fast(fr.env, 0, d.x, d.y, d.z, e);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float v = e[k] / (e[k] + 1.0f);
@@ -104,19 +115,9 @@ RDR_DEV void shade_sky(const DFrame& fr, int px, int py, float out[4]) {
     out[3] = 1.0f;
 }
 
-// basic.vert for the triangle's three vertices + pbr.frag at the centre of pixel (px,py)
-#ifndef RDR_SHADE_INLINE
-#define RDR_SHADE_INLINE 0
-#endif
-#ifndef RDR_SHADE_WAVES
-#define RDR_SHADE_WAVES 1
-#endif
-#if RDR_SHADE_INLINE
-__device__ __forceinline__ void shade_fragment(
-#else
-__device__ __noinline__ void shade_fragment(
-#endif
-const DFrame& fr, const float* srgb, const DDraw& d, uint32_t tri, int px, int py, float out[4]) {
+// basic.vert for the three vertices of one triangle (basic.vert:36-49) and the
+// homogeneous barycentric planes of its clip-space positions.
+RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DShadeTri& o) {
     const DPrim& pr = fr.prims[d.prim];
     const uint32_t* ip = fr.idx + pr.first_index + 3u * tri;
     const uint32_t vi[3] = {pr.first_vertex + ip[0], pr.first_vertex + ip[1], pr.first_vertex + ip[2]};
@@ -124,65 +125,74 @@ const DFrame& fr, const float* srgb, const DDraw& d, uint32_t tri, int px, int p
     F4 cp[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { op[k] = fr.pos[vi[k]]; cp[k] = xform_point(d.mvp, op[k].x, op[k].y, op[k].z); }
-
-    // ---- perspective-correct barycentrics (double) at (px,py), (px+1,py), (px,py+1)
-    double A[3], B[3], C[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const F4 p = cp[(k + 1) % 3], q = cp[(k + 2) % 3];
-        A[k] = (double)p.y * (double)q.w - (double)q.y * (double)p.w;
-        B[k] = (double)q.x * (double)p.w - (double)p.x * (double)q.w;
-        C[k] = (double)p.x * (double)q.y - (double)q.x * (double)p.y;
+        o.A[k] = (double)p.y * (double)q.w - (double)q.y * (double)p.w;
+        o.B[k] = (double)q.x * (double)p.w - (double)p.x * (double)q.w;
+        o.C[k] = (double)p.x * (double)q.y - (double)q.x * (double)p.y;
     }
-    const float x0 = fmaf((float)px + 0.5f, fr.inv2W, -1.0f), x1 = fmaf((float)px + 1.5f, fr.inv2W, -1.0f);
-    const float y0 = fmaf((float)py + 0.5f, fr.inv2H, -1.0f), y1 = fmaf((float)py + 1.5f, fr.inv2H, -1.0f);
-    float lam[3][3];
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        const double xn = e == 1 ? x1 : x0, yn = e == 2 ? y1 : y0;
-        double l[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) l[k] = fma(A[k], xn, fma(B[k], yn, C[k]));
-        const double sum = (l[0] + l[1]) + l[2];
-#pragma unroll
-        for (int k = 0; k < 3; k++) lam[e][k] = (float)(l[k] / sum);
-    }
-
-    // ---- vertex outputs
-    F3 wp[3], nrm[3], tan[3], bit[3];
-    float tu[3], tv[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const F4 w4 = xform_point(d.model, op[k].x, op[k].y, op[k].z);
-        wp[k] = w4.w == 1.0f ? f3(w4.x, w4.y, w4.z) : f3(w4.x / w4.w, w4.y / w4.w, w4.z / w4.w);
+        const F3 wp = w4.w == 1.0f ? f3(w4.x, w4.y, w4.z) : f3(w4.x / w4.w, w4.y / w4.w, w4.z / w4.w);
         const DVertexAttr a = fr.attr[vi[k]];
-        nrm[k] = fast_normalize(xform_dir(d.model, a.nx, a.ny, a.nz));
-        tan[k] = fast_normalize(xform_dir(d.model, a.tx, a.ty, a.tz));
-        bit[k] = fast_normalize(xform_dir(d.model, a.bx, a.by, a.bz));
-        tu[k] = a.u; tv[k] = a.v;
+        const F3 n = fast_normalize(xform_dir(d.model, a.nx, a.ny, a.nz));
+        const F3 t = fast_normalize(xform_dir(d.model, a.tx, a.ty, a.tz));
+        const F3 b = fast_normalize(xform_dir(d.model, a.bx, a.by, a.bz));
+        o.wp[k] = wp.x; o.wp[3 + k] = wp.y; o.wp[6 + k] = wp.z;
+        o.nrm[k] = n.x; o.nrm[3 + k] = n.y; o.nrm[6 + k] = n.z;
+        o.tan[k] = t.x; o.tan[3 + k] = t.y; o.tan[6 + k] = t.z;
+        o.bit[k] = b.x; o.bit[3 + k] = b.y; o.bit[6 + k] = b.z;
+        o.uv[k] = a.u; o.uv[3 + k] = a.v;
     }
-    const F3 P = f3(interp3(lam[0], wp[0].x, wp[1].x, wp[2].x), interp3(lam[0], wp[0].y, wp[1].y, wp[2].y), interp3(lam[0], wp[0].z, wp[1].z, wp[2].z));
-    const F3 Nv = f3(interp3(lam[0], nrm[0].x, nrm[1].x, nrm[2].x), interp3(lam[0], nrm[0].y, nrm[1].y, nrm[2].y), interp3(lam[0], nrm[0].z, nrm[1].z, nrm[2].z));
-    const F3 Tv = f3(interp3(lam[0], tan[0].x, tan[1].x, tan[2].x), interp3(lam[0], tan[0].y, tan[1].y, tan[2].y), interp3(lam[0], tan[0].z, tan[1].z, tan[2].z));
-    const F3 Bv = f3(interp3(lam[0], bit[0].x, bit[1].x, bit[2].x), interp3(lam[0], bit[0].y, bit[1].y, bit[2].y), interp3(lam[0], bit[0].z, bit[1].z, bit[2].z));
-    const float u0 = interp3(lam[0], tu[0], tu[1], tu[2]), v0 = interp3(lam[0], tv[0], tv[1], tv[2]);
-    const float dudx = interp3(lam[1], tu[0], tu[1], tu[2]) - u0, dvdx = interp3(lam[1], tv[0], tv[1], tv[2]) - v0;
-    const float dudy = interp3(lam[2], tu[0], tu[1], tu[2]) - u0, dvdy = interp3(lam[2], tv[0], tv[1], tv[2]) - v0;
+    o.prim = d.prim;
+}
+
+// pbr.frag at the centre of pixel (px,py) of the triangle whose vertex-stage outputs are in T
+RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri& T, int px, int py, float out[4]) {
+    // ---- perspective-correct barycentrics (double) at (px,py), (px+1,py), (px,py+1)
+    const float x0 = fmaf((float)px + 0.5f, fr.inv2W, -1.0f), x1 = fmaf((float)px + 1.5f, fr.inv2W, -1.0f);
+    const float y0 = fmaf((float)py + 0.5f, fr.inv2H, -1.0f), y1 = fmaf((float)py + 1.5f, fr.inv2H, -1.0f);
+    float lam[3][3];
+    {
+        double A[3], B[3], C[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { A[k] = T.A[k]; B[k] = T.B[k]; C[k] = T.C[k]; }
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const double xn = e == 1 ? x1 : x0, yn = e == 2 ? y1 : y0;
+            double l[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) l[k] = fma(A[k], xn, fma(B[k], yn, C[k]));
+            const double inv = 1.0 / ((l[0] + l[1]) + l[2]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) lam[e][k] = (float)(l[k] * inv);
+        }
+    }
+    const F3 P = f3(interp3(lam[0], T.wp[0], T.wp[1], T.wp[2]), interp3(lam[0], T.wp[3], T.wp[4], T.wp[5]), interp3(lam[0], T.wp[6], T.wp[7], T.wp[8]));
+    const F3 Nv = f3(interp3(lam[0], T.nrm[0], T.nrm[1], T.nrm[2]), interp3(lam[0], T.nrm[3], T.nrm[4], T.nrm[5]), interp3(lam[0], T.nrm[6], T.nrm[7], T.nrm[8]));
+    const F3 Tv = f3(interp3(lam[0], T.tan[0], T.tan[1], T.tan[2]), interp3(lam[0], T.tan[3], T.tan[4], T.tan[5]), interp3(lam[0], T.tan[6], T.tan[7], T.tan[8]));
+    const F3 Bv = f3(interp3(lam[0], T.bit[0], T.bit[1], T.bit[2]), interp3(lam[0], T.bit[3], T.bit[4], T.bit[5]), interp3(lam[0], T.bit[6], T.bit[7], T.bit[8]));
+    const float u0 = interp3(lam[0], T.uv[0], T.uv[1], T.uv[2]), v0 = interp3(lam[0], T.uv[3], T.uv[4], T.uv[5]);
+    const float dudx = interp3(lam[1], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdx = interp3(lam[1], T.uv[3], T.uv[4], T.uv[5]) - v0;
+    const float dudy = interp3(lam[2], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdy = interp3(lam[2], T.uv[3], T.uv[4], T.uv[5]) - v0;
+    const DPrim& pr = fr.prims[T.prim];
     const DMaterial& mt = pr.mat;
 
     // ---- pbr.frag main()
     float t[4];
-    tex_sample(srgb, fr.textures[mt.tex[0] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[0]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<15>(srgb, fr.textures[mt.tex[0] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[0]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float albedo[4] = {t[0] * mt.base_color[0], t[1] * mt.base_color[1], t[2] * mt.base_color[2], t[3] * mt.base_color[3]};
     if (mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
-    tex_sample(srgb, fr.textures[mt.tex[2] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[2]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<6>(srgb, fr.textures[mt.tex[2] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[2]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
     const float roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
-    tex_sample(srgb, fr.textures[mt.tex[3] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[3]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<1>(srgb, fr.textures[mt.tex[3] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[3]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float ao = t[0] * mt.ao;
-    tex_sample(srgb, fr.textures[mt.tex[4] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[4]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<7>(srgb, fr.textures[mt.tex[4] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[4]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float emissive[3] = {t[0] * mt.emissive[0], t[1] * mt.emissive[1], t[2] * mt.emissive[2]};
-    tex_sample(srgb, fr.textures[mt.tex[1] == 0xFFFFFFFFu ? fr.tex_normal : mt.tex[1]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<7>(srgb, fr.textures[mt.tex[1] == 0xFFFFFFFFu ? fr.tex_normal : mt.tex[1]], u0, v0, dudx, dvdx, dudy, dvdy, t);
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
     const float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f, nz = t[2] * 2.0f - 1.0f;
     const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
@@ -196,20 +206,22 @@ const DFrame& fr, const float* srgb, const DDraw& d, uint32_t tri, int px, int p
     F3 Lo = f3(0.0f, 0.0f, 0.0f);
 
     // ---- point lights (pbr.frag:123-160)
-    const float far = 100.0f, near = 0.1f;
+    // depth of the cube-face projection (near .1, far 100): (far - far*near/d) / (far - near) = c0 - c1 / d
+    const float c0 = 100.0f / (100.0f - 0.1f), c1 = (100.0f * 0.1f) / (100.0f - 0.1f);
     for (uint32_t li = 0; li < fr.n_lights; li++) {
         const DPointLight pl = fr.lights[li];
         const F3 Lv = f3(pl.px, pl.py, pl.pz) - P;
-        const float dist = sqrtf(dot3(Lv, Lv));
-        const float attenuation = 1.0f / (dist * dist);
+        const float d2 = dot3(Lv, Lv);  // distance^2
+        // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
+        if (fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2) continue;
+        const float attenuation = fast_rcp(d2);
         const F3 radiance = f3(pl.ix * attenuation, pl.iy * attenuation, pl.iz * attenuation);
-        if (fmaxf(radiance.x, fmaxf(radiance.y, radiance.z)) <= 1e-3f) continue;
-        float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
-        lightDepth = (far - far * near / lightDepth) / (far - near);
         if ((pl.flags & 1u) && (pl.flags & 2u)) {
-            const float shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, lightDepth);
+            const float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
+            const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
+            const float shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, ref);
             if (shadowTest < 1e-3f) continue;
-            const F3 r = brdf(radiance, fast_normalize(Lv), N, V, alb, roughness, metallic, F0);
+            const F3 r = brdf(radiance, Lv * __builtin_amdgcn_rsqf(d2), N, V, alb, roughness, metallic, F0);
             Lo = Lo + r * shadowTest;
         } else {
             Lo = Lo + brdf(radiance, Lv, N, V, alb, roughness, metallic, F0);  // L not normalised (pbr.frag:158)
@@ -242,8 +254,8 @@ const DFrame& fr, const float* srgb, const DDraw& d, uint32_t tri, int px, int p
         const float fl = floorf(lod), ff = lod - fl;
         const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, fr.prefiltered.levels - 1u);
         float s0[3], s1[3], irr[3], lut[2];
-        cube_sample(fr.prefiltered, l0, Rv.x, Rv.y, Rv.z, s0);
-        cube_sample(fr.prefiltered, l1, Rv.x, Rv.y, Rv.z, s1);
+        cube_sample_fast(fr.prefiltered, l0, Rv.x, Rv.y, Rv.z, s0);
+        cube_sample_fast(fr.prefiltered, l1, Rv.x, Rv.y, Rv.z, s1);
         {
             const int w = (int)fr.lut_w, h = (int)fr.lut_h;
             const float lu = NdotV * (float)w - 0.5f, lv = roughness * (float)h - 0.5f;
@@ -261,7 +273,7 @@ const DFrame& fr, const float* srgb, const DDraw& d, uint32_t tri, int px, int p
                 lut[k] = (1.0f - b) * top + b * bot;
             }
         }
-        cube_sample(fr.irradiance, 0, N.x, N.y, N.z, irr);
+        cube_sample_fast(fr.irradiance, 0, N.x, N.y, N.z, irr);
         const float x = 1.0f - clampf(NdotV, 0.0f, 1.0f);
         const float x2 = x * x, x5 = x2 * x2 * x;
         const float F[3] = {F0.x + (1.0f - F0.x) * x5, F0.y + (1.0f - F0.y) * x5, F0.z + (1.0f - F0.z) * x5};
@@ -289,62 +301,123 @@ RDR_DEV uint32_t find_draw_by_tri(const uint32_t* __restrict__ first_tri, uint32
     return lo;
 }
 
+// One thread per triangle of a view's draw list (index = visibility id): vertex stage, stored for the fragments.
+// `recs` are the rasteriser's records of the same triangles; a triangle that set-up dropped (clipped away,
+// culled, degenerate) can never be visible and is skipped.
+__global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ frp, const DDraw* __restrict__ draws,
+                                                     const uint32_t* __restrict__ first_tri, uint32_t n_draws, uint32_t n_tris,
+                                                     const DTriRec* __restrict__ recs, DShadeTri* __restrict__ out) {
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= n_tris) return;
+    if ((recs[id].n_view & 255u) == 0u) return;
+    const uint32_t di = find_draw_by_tri(first_tri, n_draws, id);
+    DShadeTri t;
+    shade_tri_setup(*frp, draws[di], id - first_tri[di], t);
+    t._pad[0] = t._pad[1] = t._pad[2] = 0u;
+    out[id] = t;
+}
+
+#define SHADE_NO_FRAGMENT 0xFFu
+
 // Opaque draws + skybox. S == 1: writes hdr. S == 4: writes the four sample
 // colours when `samples_out` is given (a blended pass follows), else resolves
 // straight into hdr.
 template <int S>
-__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFrame* __restrict__ frp, const DDraw* __restrict__ draws,
-                                                      const uint32_t* __restrict__ first_tri, uint32_t n_draws,
+__global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
                                                       const float* __restrict__ depth, const uint32_t* __restrict__ vis,
                                                       uint2* __restrict__ hdr, uint2* __restrict__ samples_out) {
     __shared__ float lds_srgb[256];
+    __shared__ uint32_t lds_frag_id[256 * S];   // triangle id of fragment f
+    __shared__ uint8_t lds_frag_px[256 * S];    // its pixel = the thread index that owns the pixel
+    __shared__ uint2 lds_frag_col[256 * S];     // shaded colour, RGBA16F
+    __shared__ uint32_t lds_wave_total[4];
     const DFrame& fr = *frp;
     lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
-    __syncthreads();
     const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
     const int tx = (int)(blockIdx.x % tiles_x), ty = (int)(blockIdx.x / tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
-    if (px >= (int)fr.W || py >= (int)fr.H) return;
+    const bool in_view = px < (int)fr.W && py < (int)fr.H;
     const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
+
+    // ---- classify the samples of this pixel: sky, or the u-th distinct triangle of the pixel
     uint32_t ids[S];
-    float cols[S][4];
-    int n_unique = 0;
-    bool have_sky = false;
-    float sky[4];
-    float sc[S][4];
+    uint32_t slot[S];  // SHADE_NO_FRAGMENT = sky, else index among the pixel's distinct triangles
+    uint32_t n_unique = 0;
 #pragma unroll
     for (int s = 0; s < S; s++) {
+        slot[s] = SHADE_NO_FRAGMENT;
+        if (!in_view) continue;
         const uint32_t id = vis[s * plane_px + o];
         const float zd = depth[s * plane_px + o];
-        if (id == 0xFFFFFFFFu || zd >= 1.0f) {
-            if (!have_sky) { shade_sky(fr, px, py, sky); have_sky = true; }
+        if (id == 0xFFFFFFFFu || zd >= 1.0f) continue;
+        uint32_t u = n_unique;
 #pragma unroll
-            for (int k = 0; k < 4; k++) sc[s][k] = sky[k];
-        } else {
-            int u = 0;
-            for (; u < n_unique; u++) if (ids[u] == id) break;
-            if (u == n_unique) {
-                const uint32_t di = find_draw_by_tri(first_tri, n_draws, id);
-                shade_fragment(fr, lds_srgb, draws[di], id - first_tri[di], px, py, cols[u]);
-                ids[u] = id;
-                n_unique++;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) sc[s][k] = cols[u][k];
-        }
+        for (int k = S - 1; k >= 0; k--) if ((uint32_t)k < n_unique && ids[k] == id) u = (uint32_t)k;
+        if (u == n_unique) { ids[n_unique] = id; n_unique++; }
+        slot[s] = u;
     }
+
+    // ---- exclusive prefix sum of n_unique (0..4) over the block: three ballots per wave, then the wave totals
+    uint32_t before = 0, wave_total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 3; bit++) {
+        const unsigned long long m = __ballot((n_unique >> bit) & 1u);
+        before += (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) << bit;
+        wave_total += (uint32_t)__popcll(m) << bit;
+    }
+    if (lane == 0) lds_wave_total[wave] = wave_total;
+    __syncthreads();
+    uint32_t n_frag = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) before += lds_wave_total[w];
+        n_frag += lds_wave_total[w];
+    }
+#pragma unroll
+    for (int k = 0; k < S; k++)
+        if ((uint32_t)k < n_unique) { lds_frag_id[before + k] = ids[k]; lds_frag_px[before + k] = (uint8_t)threadIdx.x; }
+    __syncthreads();
+
+    // ---- shade the fragment list densely
+    for (uint32_t f = threadIdx.x; f < n_frag; f += 256u) {
+        const uint32_t id = lds_frag_id[f], t = lds_frag_px[f];
+        const int fw = (int)(t >> 6), fl = (int)(t & 63u);
+        const int fx = tx * RDR_TILE + (fw & 1) * 8 + (fl & 7), fy = ty * RDR_TILE + (fw >> 1) * 8 + (fl >> 3);
+        float c[4];
+        shade_fragment(fr, lds_srgb, tris[id], fx, fy, c);
+        lds_frag_col[f] = pack_half4(c[0], c[1], c[2], c[3]);
+    }
+    __syncthreads();
+    if (!in_view) return;
+
+    // ---- per pixel: sky where needed, gather the sample colours, store or resolve
+    bool any_sky = false;
+#pragma unroll
+    for (int s = 0; s < S; s++) any_sky = any_sky || slot[s] == SHADE_NO_FRAGMENT;
+    uint2 sky_packed = make_uint2(0u, 0u);
+    if (any_sky) {
+        float sky[4];
+        shade_sky(fr, px, py, sky);
+        sky_packed = pack_half4(sky[0], sky[1], sky[2], sky[3]);
+    }
+    uint2 sc[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) sc[s] = slot[s] == SHADE_NO_FRAGMENT ? sky_packed : lds_frag_col[before + slot[s]];
     if (S == 1) {
-        hdr[o] = pack_half4(sc[0][0], sc[0][1], sc[0][2], sc[0][3]);
+        hdr[o] = sc[0];
     } else if (samples_out) {
 #pragma unroll
-        for (int s = 0; s < S; s++) samples_out[s * plane_px + o] = pack_half4(sc[s][0], sc[s][1], sc[s][2], sc[s][3]);
+        for (int s = 0; s < S; s++) samples_out[s * plane_px + o] = sc[s];
     } else {
         float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int s = 0; s < S; s++)
+        for (int s = 0; s < S; s++) {
+            float c[4];
+            unpack_half4(sc[s], c[0], c[1], c[2], c[3]);
 #pragma unroll
-            for (int k = 0; k < 4; k++) sum[k] += quantize_half(sc[s][k]);
+            for (int k = 0; k < 4; k++) sum[k] += c[k];
+        }
         hdr[o] = pack_half4(sum[0] * (1.0f / S), sum[1] * (1.0f / S), sum[2] * (1.0f / S), sum[3] * (1.0f / S));
     }
 }
@@ -371,8 +444,7 @@ __global__ void __launch_bounds__(256) k_resolve4(const uint2* __restrict__ samp
 // into the colour target, in list order (VulkanRenderer.cpp:862-866, 1059-1062).
 template <int S>
 __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__ frp, const DView* __restrict__ views,
-                                                      const DDraw* __restrict__ draws, const uint32_t* __restrict__ first_tri,
-                                                      uint32_t n_draws, const DTriRec* __restrict__ recs,
+                                                      const DShadeTri* __restrict__ tris, const DTriRec* __restrict__ recs,
                                                       const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
                                                       const uint32_t* __restrict__ tile_end, uint2* __restrict__ color) {
     __shared__ uint32_t lds_rec[BLEND_CHUNK * 32];
@@ -438,10 +510,8 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
                 }
             }
             if (pass) {
-                const uint32_t rid = r->id;
-                const uint32_t di = find_draw_by_tri(first_tri, n_draws, rid);
                 float src[4];
-                shade_fragment(fr, lds_srgb, draws[di], rid - first_tri[di], px, py, src);
+                shade_fragment(fr, lds_srgb, tris[r->id], px, py, src);
                 const float a = src[3];
 #pragma unroll
                 for (int s = 0; s < S; s++)
@@ -463,23 +533,27 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
 
 }  // namespace
 
-void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws,
-                         const float* depth, const uint32_t* vis, void* hdr, void* samples_out, uint32_t W, uint32_t H) {
+void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,
+                        const DTriRec* recs, DShadeTri* out) {
+    if (!n_tris) return;
+    hipLaunchKernelGGL(k_shade_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, fr, draws, first_tri, n_draws, n_tris, recs, out);
+}
+void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
+                         void* hdr, void* samples_out, uint32_t W, uint32_t H) {
     const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
     if (samples == 1)
-        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(tiles), dim3(256), 0, s, fr, draws, first_tri, n_draws, depth, vis, (uint2*)hdr, (uint2*)samples_out);
+        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out);
     else
-        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(tiles), dim3(256), 0, s, fr, draws, first_tri, n_draws, depth, vis, (uint2*)hdr, (uint2*)samples_out);
+        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out);
 }
 void launch_resolve4(hipStream_t s, const void* samples, void* hdr, uint32_t n) {
     hipLaunchKernelGGL(k_resolve4, dim3((n + 255) / 256), dim3(256), 0, s, (const uint2*)samples, (uint2*)hdr, n);
 }
-void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* views, const DDraw* draws, const uint32_t* first_tri,
-                         uint32_t n_draws, const DTriRec* recs, const uint32_t* sorted_vals, const uint32_t* tile_start,
-                         const uint32_t* tile_end, uint32_t n_tiles, void* color) {
+void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* views, const DShadeTri* tris, const DTriRec* recs,
+                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color) {
     if (!n_tiles) return;
     if (samples == 1)
-        hipLaunchKernelGGL(k_raster_blend<1>, dim3(n_tiles), dim3(256), 0, s, fr, views, draws, first_tri, n_draws, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
+        hipLaunchKernelGGL(k_raster_blend<1>, dim3(n_tiles), dim3(256), 0, s, fr, views, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
     else
-        hipLaunchKernelGGL(k_raster_blend<4>, dim3(n_tiles), dim3(256), 0, s, fr, views, draws, first_tri, n_draws, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
+        hipLaunchKernelGGL(k_raster_blend<4>, dim3(n_tiles), dim3(256), 0, s, fr, views, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
 }

@@ -122,6 +122,7 @@ struct rdr_ctx {
     // raster scratch
     DevBuf d_views, d_draws, d_draw_first, d_first_tri, d_recs, d_pair_count, d_scan, d_hist, d_tile_start, d_tile_end, d_counters, d_frame;
     DevBuf d_keys[2], d_vals[2];
+    DevBuf d_shade_tris;  // DShadeTri per triangle of the view being shaded
     PinBuf h_stage, h_read;
     std::vector<DDraw> main_draws;  // opaque draws of the last frame (kept for read-backs)
 
@@ -658,7 +659,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_views, &c->d_draws,
                       &c->d_draw_first, &c->d_first_tri, &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start, &c->d_tile_end,
-                      &c->d_counters, &c->d_frame, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
+                      &c->d_counters, &c->d_frame, &c->d_shade_tris, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release();
@@ -987,6 +988,13 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     c->stats.draws_main = (uint32_t)(c->main_draws.size() + blended.size());
     RDR_TRY(raster_batch(c, b));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    // the main view is the last view of the batch: its triangle records are the tail of d_recs, in visibility-id order
+    uint32_t main_first_instance = 0, n_main_tris = 0;
+    if (!c->main_draws.empty()) {
+        main_first_instance = b.draws[first_main_draw].first_instance;
+        const DDraw& last = c->main_draws.back();
+        n_main_tris = last.first_tri_id + c->prims[last.prim].tri_count;
+    }
 
     // ---- frame constants
     {
@@ -1046,10 +1054,12 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     const bool have_blend = !blended.empty();
     void* color_target = c->d_hdr.p;
     if (S == 4 && have_blend) { HIP_TRY(c->d_samples.ensure(n * 4 * 8)); color_target = c->d_samples.p; }
+    HIP_TRY(c->d_shade_tris.ensure(std::max<size_t>(n_main_tris, 1) * sizeof(DShadeTri)));
+    launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>(), c->d_first_tri.as<uint32_t>(),
+                       (uint32_t)c->main_draws.size(), n_main_tris, c->d_recs.as<DTriRec>() + main_first_instance, c->d_shade_tris.as<DShadeTri>());
     HIP_TRY(hipEventRecord(c->ev[6], c->stream));
-    launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>(), c->d_first_tri.as<uint32_t>(),
-                        (uint32_t)c->main_draws.size(), c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
-                        (S == 4 && have_blend) ? c->d_samples.p : nullptr, W, H);
+    launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_shade_tris.as<DShadeTri>(), c->d_depth.as<float>(),
+                        c->d_vis.as<uint32_t>(), c->d_hdr.p, (S == 4 && have_blend) ? c->d_samples.p : nullptr, W, H);
     HIP_TRY(hipEventRecord(c->ev[7], c->stream));
     HIP_TRY(hipGetLastError());
 
@@ -1063,9 +1073,14 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         int cur = 0;
         RDR_TRY(bin_batch(c, bb, &n_tiles, &cur));
         c->stats.views -= 1;  // the blended draws belong to the main view, already counted
-        launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>(), c->d_draws.as<DDraw>(),
-                            c->d_first_tri.as<uint32_t>(), (uint32_t)bb.draws.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                            c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, color_target);
+        const DDraw& last = bb.draws.back();
+        const uint32_t n_blend_tris = last.first_tri_id + c->prims[last.prim].tri_count;
+        HIP_TRY(c->d_shade_tris.ensure((size_t)n_blend_tris * sizeof(DShadeTri)));  // the opaque pass is done with it (stream order)
+        launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>(), c->d_first_tri.as<uint32_t>(),
+                           (uint32_t)bb.draws.size(), n_blend_tris, c->d_recs.as<DTriRec>(), c->d_shade_tris.as<DShadeTri>());
+        launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>(), c->d_shade_tris.as<DShadeTri>(),
+                            c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
+                            c->d_tile_end.as<uint32_t>(), n_tiles, color_target);
         if (S == 4) launch_resolve4(c->stream, c->d_samples.p, c->d_hdr.p, (uint32_t)n);
         HIP_TRY(hipGetLastError());
     }

@@ -81,6 +81,17 @@ struct DTriRec {
     uint32_t _pad2[2];
 };  // 128 bytes
 
+// Vertex-stage outputs of one main-view triangle (basic.vert), written once per
+// frame by the shading set-up kernel and read by every fragment of the triangle.
+struct DShadeTri {
+    double A[3], B[3], C[3];  // homogeneous barycentric planes: l_k(x,y) = A_k x + B_k y + C_k in NDC
+    float wp[9];              // world position, component-major: x0 x1 x2 y0 y1 y2 z0 z1 z2
+    float nrm[9], tan[9], bit[9];
+    float uv[6];              // u0 u1 u2 v0 v1 v2
+    uint32_t prim;
+    uint32_t _pad[3];
+};  // 256 bytes
+
 struct DPointLight {
     float px, py, pz;
     float ix, iy, iz;
