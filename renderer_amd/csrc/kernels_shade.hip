@@ -438,10 +438,21 @@ __global__ void __launch_bounds__(256) k_resolve4(const uint2* __restrict__ samp
 }
 
 #define BLEND_CHUNK 64
+#define BLEND_LIST 256  // fragments a wave collects before it shades and blends them
+#define BLEND_NONE 0xFFFFu
 
-// Blended (MASK + BLEND) draws, back to front: same tile walk as k_raster,
-// but every fragment that passes the depth test is shaded at once and blended
-// into the colour target, in list order (VulkanRenderer.cpp:862-866, 1059-1062).
+// Blended (MASK + BLEND) draws, back to front: same tile walk as k_raster, the
+// fragments that pass the depth test are blended into the colour target in list
+// order (VulkanRenderer.cpp:862-866, 1059-1062).
+//
+// A wave owns an 8x8 quadrant, so the order of the fragments of a pixel is the
+// order in which its wave meets the triangles. Shading each triangle as it is
+// met would run the whole of pbr.frag for the few lanes a small triangle
+// covers; instead the wave appends (triangle, lane, sample mask) to a list in
+// LDS - depth is tested and written at once, it does not depend on shading -
+// and when the list fills up (or the tile is done) shades it densely, one
+// fragment per lane, then every lane walks the chain of its own fragments in
+// order and blends them. No block-level synchronisation is involved.
 template <int S>
 __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__ frp, const DView* __restrict__ views,
                                                       const DShadeTri* __restrict__ tris, const DTriRec* __restrict__ recs,
@@ -450,6 +461,10 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
     __shared__ uint32_t lds_rec[BLEND_CHUNK * 32];
     __shared__ uint32_t lds_ids[BLEND_CHUNK];
     __shared__ float lds_srgb[256];
+    __shared__ uint32_t lds_f_id[4][BLEND_LIST];
+    __shared__ uint16_t lds_f_meta[4][BLEND_LIST];  // lane | sample mask << 8
+    __shared__ uint16_t lds_f_next[4][BLEND_LIST];  // next fragment of the same lane
+    __shared__ float4 lds_f_col[4][BLEND_LIST];
     const DFrame& fr = *frp;
     lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
     const DView vw = views[0];
@@ -470,6 +485,40 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
         if (in_view) unpack_half4(color[s * plane_px + o], col[s][0], col[s][1], col[s][2], col[s][3]);
         else col[s][0] = col[s][1] = col[s][2] = col[s][3] = 0.0f;
     }
+    uint32_t* f_id = lds_f_id[wave];
+    uint16_t* f_meta = lds_f_meta[wave];
+    uint16_t* f_next = lds_f_next[wave];
+    float4* f_col = lds_f_col[wave];
+    uint32_t n_list = 0;                       // wave-uniform
+    uint32_t my_first = BLEND_NONE, my_last = BLEND_NONE;
+
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t f = (uint32_t)lane; f < n_list; f += 64u) {
+            const uint32_t fl = f_meta[f] & 63u;
+            float c[4];
+            shade_fragment(fr, lds_srgb, tris[f_id[f]], qx0 + (int)(fl & 7u), qy0 + (int)(fl >> 3), c);
+            f_col[f] = make_float4(c[0], c[1], c[2], c[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t f = my_first; f != BLEND_NONE; f = f_next[f]) {
+            const float4 src = f_col[f];
+            const uint32_t pass = (uint32_t)f_meta[f] >> 8;
+            const float a = src.w;
+#pragma unroll
+            for (int s = 0; s < S; s++)
+                if (pass & (1u << s)) {
+                    col[s][0] = quantize_half(src.x * a + col[s][0] * (1.0f - a));
+                    col[s][1] = quantize_half(src.y * a + col[s][1] * (1.0f - a));
+                    col[s][2] = quantize_half(src.z * a + col[s][2] * (1.0f - a));
+                    col[s][3] = quantize_half(a);
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        n_list = 0;
+        my_first = my_last = BLEND_NONE;
+    };
+
     const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
     for (uint32_t base = begin; base < end; base += BLEND_CHUNK) {
         const uint32_t cnt = min((uint32_t)BLEND_CHUNK, end - base);
@@ -484,43 +533,48 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
             hit = r->px0 <= qx0 + 7 && r->px1 >= qx0 && r->py0 <= qy0 + 7 && r->py1 >= qy0;
         }
         unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int ri = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const DTriRec* r = (const DTriRec*)(lds_rec + ri * 32);
-            const int n = (int)(r->n_view & 255u);
-            const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
-            uint32_t pass = 0;
+        const bool last_chunk = base + BLEND_CHUNK >= end;
+        for (;;) {
+            const bool more = mask != 0ull;
+            if (more) {
+                const int ri = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const DTriRec* r = (const DTriRec*)(lds_rec + ri * 32);
+                const int n = (int)(r->n_view & 255u);
+                const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
+                uint32_t pass = 0;
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                const int Px = 256 * px + (S == 1 ? 128 : sxo[s]), Py = 256 * py + (S == 1 ? 128 : syo[s]);
-                bool inside = in_view;
-                for (int i = 0; i < n; i++) {
-                    const int j = (i + 1 == n) ? 0 : i + 1;
-                    const int Xi = r->X[i], Yi = r->Y[i];
-                    const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
-                    const long long E = (long long)dX * (long long)(Py - Yi) - (long long)dY * (long long)(Px - Xi);
-                    const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
-                    inside = inside && (E >= bias);
-                }
-                if (inside) {
-                    float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
-                    zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
-                    if (zz < z[s]) { z[s] = zz; pass |= 1u << s; }
-                }
-            }
-            if (pass) {
-                float src[4];
-                shade_fragment(fr, lds_srgb, tris[r->id], px, py, src);
-                const float a = src[3];
-#pragma unroll
-                for (int s = 0; s < S; s++)
-                    if (pass & (1u << s)) {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) col[s][k] = quantize_half(src[k] * a + col[s][k] * (1.0f - a));
-                        col[s][3] = quantize_half(a);
+                for (int s = 0; s < S; s++) {
+                    const int Px = 256 * px + (S == 1 ? 128 : sxo[s]), Py = 256 * py + (S == 1 ? 128 : syo[s]);
+                    bool inside = in_view;
+                    for (int i = 0; i < n; i++) {
+                        const int j = (i + 1 == n) ? 0 : i + 1;
+                        const int Xi = r->X[i], Yi = r->Y[i];
+                        const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                        const long long E = (long long)dX * (long long)(Py - Yi) - (long long)dY * (long long)(Px - Xi);
+                        const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+                        inside = inside && (E >= bias);
                     }
+                    if (inside) {
+                        float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
+                        zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
+                        if (zz < z[s]) { z[s] = zz; pass |= 1u << s; }
+                    }
+                }
+                const unsigned long long pm = __ballot(pass != 0u);
+                if (pass) {
+                    const uint32_t f = n_list + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                    f_id[f] = r->id;
+                    f_meta[f] = (uint16_t)((uint32_t)lane | (pass << 8));
+                    f_next[f] = (uint16_t)BLEND_NONE;
+                    if (my_last != BLEND_NONE) f_next[my_last] = (uint16_t)f; else my_first = f;
+                    my_last = f;
+                }
+                n_list += (uint32_t)__popcll(pm);
             }
+            // the single place where the wave shades and blends what it has collected
+            if (n_list + 64u > BLEND_LIST || (!more && last_chunk && n_list != 0u)) flush();
+            if (!more) break;
         }
     }
     if (!in_view) return;
