@@ -41,10 +41,10 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DT
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,
                         const DTriRec* recs, DShadeTri* out);
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
-                         void* hdr, void* samples_out, uint32_t W, uint32_t H);
-void launch_resolve4(hipStream_t s, const void* samples, void* hdr, uint32_t n);
-void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* views, const DShadeTri* tris, const DTriRec* recs,
-                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color);
+                         void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H);
+void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,
+                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
+                         void* hdr);
 
 // kernels_ibl.hip
 void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n);

@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views,
     for (uint32_t k = first_view + 1; k < n_views; k++) if (views[k].tile_base <= tile) v = k;
     const DView vw = views[v];
     if ((S == 4) != (vw.samples == 4u)) return;  // the other instantiation handles it
+    if (vw.load == 2u) return;                    // tiles of the blended pass: binned here, rasterised with their shading
     const uint32_t local_tile = tile - vw.tile_base;
     if (local_tile >= vw.tiles_x * vw.tiles_y) return;
     const int tx = (int)(local_tile % vw.tiles_x), ty = (int)(local_tile / vw.tiles_x);

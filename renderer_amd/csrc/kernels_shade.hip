@@ -319,13 +319,15 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 
 #define SHADE_NO_FRAGMENT 0xFFu
 
-// Opaque draws + skybox. S == 1: writes hdr. S == 4: writes the four sample
-// colours when `samples_out` is given (a blended pass follows), else resolves
-// straight into hdr.
+// Opaque draws + skybox. S == 1: writes hdr. S == 4: resolves straight into
+// hdr, except in tiles whose blended-pass triangle list is not empty
+// (blend_start < blend_end): those keep their four sample colours in
+// `samples_out` for k_raster_blend, which resolves them afterwards.
 template <int S>
 __global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
                                                       const float* __restrict__ depth, const uint32_t* __restrict__ vis,
-                                                      uint2* __restrict__ hdr, uint2* __restrict__ samples_out) {
+                                                      uint2* __restrict__ hdr, uint2* __restrict__ samples_out,
+                                                      const uint32_t* __restrict__ blend_start, const uint32_t* __restrict__ blend_end) {
     __shared__ float lds_srgb[256];
     __shared__ uint32_t lds_frag_id[256 * S];   // triangle id of fragment f
     __shared__ uint8_t lds_frag_px[256 * S];    // its pixel = the thread index that owns the pixel
@@ -404,9 +406,10 @@ __global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__
     uint2 sc[S];
 #pragma unroll
     for (int s = 0; s < S; s++) sc[s] = slot[s] == SHADE_NO_FRAGMENT ? sky_packed : lds_frag_col[before + slot[s]];
+    const bool keep_samples = S > 1 && samples_out && blend_start[blockIdx.x] < blend_end[blockIdx.x];
     if (S == 1) {
         hdr[o] = sc[0];
-    } else if (samples_out) {
+    } else if (keep_samples) {
 #pragma unroll
         for (int s = 0; s < S; s++) samples_out[s * plane_px + o] = sc[s];
     } else {
@@ -420,21 +423,6 @@ __global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__
         }
         hdr[o] = pack_half4(sum[0] * (1.0f / S), sum[1] * (1.0f / S), sum[2] * (1.0f / S), sum[3] * (1.0f / S));
     }
-}
-
-// Multisample resolve of the four sample colours (after the blended pass).
-__global__ void __launch_bounds__(256) k_resolve4(const uint2* __restrict__ samples, uint2* __restrict__ hdr, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        float c[4];
-        unpack_half4(samples[(size_t)s * n + i], c[0], c[1], c[2], c[3]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) sum[k] += c[k];
-    }
-    hdr[i] = pack_half4(sum[0] * 0.25f, sum[1] * 0.25f, sum[2] * 0.25f, sum[3] * 0.25f);
 }
 
 #define BLEND_CHUNK 64
@@ -457,7 +445,8 @@ template <int S>
 __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__ frp, const DView* __restrict__ views,
                                                       const DShadeTri* __restrict__ tris, const DTriRec* __restrict__ recs,
                                                       const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
-                                                      const uint32_t* __restrict__ tile_end, uint2* __restrict__ color) {
+                                                      const uint32_t* __restrict__ tile_end, uint2* __restrict__ color,
+                                                      uint2* __restrict__ hdr) {
     __shared__ uint32_t lds_rec[BLEND_CHUNK * 32];
     __shared__ uint32_t lds_ids[BLEND_CHUNK];
     __shared__ float lds_srgb[256];
@@ -467,9 +456,9 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
     __shared__ float4 lds_f_col[4][BLEND_LIST];
     const DFrame& fr = *frp;
     lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
-    const DView vw = views[0];
+    const DView vw = views[0];  // the blended view of the batch; its tile lists start at tile_base
     const uint32_t tile = blockIdx.x;
-    const uint32_t begin = tile_start[tile], end = tile_end[tile];
+    const uint32_t begin = tile_start[vw.tile_base + tile], end = tile_end[vw.tile_base + tile];
     if (begin >= end) return;
     const int tx = (int)(tile % vw.tiles_x), ty = (int)(tile / vw.tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -579,9 +568,16 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
     }
     if (!in_view) return;
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-        vw.depth[s * plane_px + o] = z[s];
-        color[s * plane_px + o] = pack_half4(col[s][0], col[s][1], col[s][2], col[s][3]);
+    for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = z[s];
+    if (S == 1) {
+        hdr[o] = pack_half4(col[0][0], col[0][1], col[0][2], col[0][3]);
+    } else {  // multisample resolve: the sample colours are RGBA16F values already
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sum[k] += col[s][k];
+        hdr[o] = pack_half4(sum[0] * (1.0f / S), sum[1] * (1.0f / S), sum[2] * (1.0f / S), sum[3] * (1.0f / S));
     }
 }
 
@@ -593,21 +589,19 @@ void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, con
     hipLaunchKernelGGL(k_shade_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, fr, draws, first_tri, n_draws, n_tris, recs, out);
 }
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
-                         void* hdr, void* samples_out, uint32_t W, uint32_t H) {
+                         void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H) {
     const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
     if (samples == 1)
-        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out);
+        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end);
     else
-        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out);
+        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end);
 }
-void launch_resolve4(hipStream_t s, const void* samples, void* hdr, uint32_t n) {
-    hipLaunchKernelGGL(k_resolve4, dim3((n + 255) / 256), dim3(256), 0, s, (const uint2*)samples, (uint2*)hdr, n);
-}
-void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* views, const DShadeTri* tris, const DTriRec* recs,
-                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color) {
+void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,
+                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
+                         void* hdr) {
     if (!n_tiles) return;
     if (samples == 1)
-        hipLaunchKernelGGL(k_raster_blend<1>, dim3(n_tiles), dim3(256), 0, s, fr, views, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
+        hipLaunchKernelGGL(k_raster_blend<1>, dim3(n_tiles), dim3(256), 0, s, fr, view, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color, (uint2*)hdr);
     else
-        hipLaunchKernelGGL(k_raster_blend<4>, dim3(n_tiles), dim3(256), 0, s, fr, views, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color);
+        hipLaunchKernelGGL(k_raster_blend<4>, dim3(n_tiles), dim3(256), 0, s, fr, view, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color, (uint2*)hdr);
 }

@@ -386,11 +386,12 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
     return RDR_OK;
 }
 
-int raster_batch(rdr_ctx* c, Batch& b) {
+int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr) {
     if (b.views.empty()) return RDR_OK;
     uint32_t n_tiles = 0;
     int cur = 0;
     RDR_TRY(bin_batch(c, b, &n_tiles, &cur));
+    if (out_cur) *out_cur = cur;
     bool s1 = false, s4 = false;
     for (const DView& v : b.views) (v.samples == 4 ? s4 : s1) = true;
     HIP_TRY(hipEventRecord(c->ev[8], c->stream));
@@ -970,7 +971,9 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     const vec3 cam_pos = c->camera.position;
     const mat4 viewproj = c->camera.view_proj();
 
-    // ---- shadow views + main opaque view, rasterised as one batch
+    // ---- shadow views, the main opaque view and the blended draws of the main view, binned as one batch.
+    // The blended "view" shares the main depth target; k_raster leaves its tiles alone (load == 2) and
+    // k_raster_blend walks them after the opaque shading.
     Batch b;
     if (c->lights_set) {
         RDR_TRY(point_shadow_views(c, cam_pos, b));
@@ -982,19 +985,31 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     b.views.push_back(make_view(c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), W, H, S, 2, 0));
     const size_t first_main_draw = b.draws.size();
     append_draws(c, opaque, viewproj, cam_pos, SORT_FRONT_TO_BACK, main_view, b.draws);
+    const size_t n_main_draws = b.draws.size() - first_main_draw;
     c->main_draws.assign(b.draws.begin() + first_main_draw, b.draws.end());
-    std::vector<DDraw> blended;
-    append_draws(c, non_opaque, viewproj, cam_pos, SORT_BACK_TO_FRONT, 0, blended);
-    c->stats.draws_main = (uint32_t)(c->main_draws.size() + blended.size());
-    RDR_TRY(raster_batch(c, b));
+    const size_t first_blend_draw = b.draws.size();
+    append_draws(c, non_opaque, viewproj, cam_pos, SORT_BACK_TO_FRONT, main_view + 1, b.draws);
+    const size_t n_blend_draws = b.draws.size() - first_blend_draw;
+    const bool have_blend = n_blend_draws != 0;
+    if (have_blend) b.views.push_back(make_view(c->d_depth.as<float>(), nullptr, W, H, S, 2, 2));
+    c->stats.draws_main = (uint32_t)(n_main_draws + n_blend_draws);
+    int cur = 0;
+    RDR_TRY(raster_batch(c, b, &cur));
+    if (have_blend) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    // the main view is the last view of the batch: its triangle records are the tail of d_recs, in visibility-id order
-    uint32_t main_first_instance = 0, n_main_tris = 0;
-    if (!c->main_draws.empty()) {
+    // triangle records of a view are contiguous in d_recs, in visibility-id order
+    uint32_t main_first_instance = 0, n_main_tris = 0, blend_first_instance = 0, n_blend_tris = 0;
+    if (n_main_draws) {
         main_first_instance = b.draws[first_main_draw].first_instance;
-        const DDraw& last = c->main_draws.back();
+        const DDraw& last = b.draws[first_blend_draw - 1];
         n_main_tris = last.first_tri_id + c->prims[last.prim].tri_count;
     }
+    if (have_blend) {
+        blend_first_instance = b.draws[first_blend_draw].first_instance;
+        const DDraw& last = b.draws.back();
+        n_blend_tris = last.first_tri_id + c->prims[last.prim].tri_count;
+    }
+    const uint32_t blend_tile_base = have_blend ? b.views.back().tile_base : 0u;
 
     // ---- frame constants
     {
@@ -1031,57 +1046,38 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         fr.tex_white = 0; fr.tex_normal = 1;
         // the staging buffer is free again: bin_batch synchronised after its uploads
         const size_t sz_l = dl.size() * sizeof(DPointLight);
-        HIP_TRY(c->h_stage.ensure(sizeof(DFrame) + sz_l + (c->main_draws.size() + 1) * (sizeof(DDraw) + 4) + 64));
+        HIP_TRY(c->h_stage.ensure(sizeof(DFrame) + sz_l + 64));
         uint8_t* st = c->h_stage.as<uint8_t>();
         memcpy(st, &fr, sizeof fr);
         memcpy(st + sizeof fr, dl.data(), sz_l);
         HIP_TRY(hipMemcpyAsync(c->d_frame.p, st, sizeof fr, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_lights.p, st + sizeof fr, sz_l, hipMemcpyHostToDevice, c->stream));
-        // main-view draws + their first triangle ids, for the shading kernels
-        const size_t nd = c->main_draws.size();
-        uint8_t* st2 = st + sizeof fr + sz_l;
-        std::vector<uint32_t> first_tri(nd + 1, 0);
-        for (size_t i = 0; i < nd; i++) first_tri[i] = c->main_draws[i].first_tri_id;
-        if (nd) memcpy(st2, c->main_draws.data(), nd * sizeof(DDraw));
-        memcpy(st2 + nd * sizeof(DDraw), first_tri.data(), (nd + 1) * 4);
-        HIP_TRY(c->d_draws.ensure(std::max<size_t>(nd, 1) * sizeof(DDraw)));
-        HIP_TRY(c->d_first_tri.ensure((nd + 1) * 4));
-        if (nd) HIP_TRY(hipMemcpyAsync(c->d_draws.p, st2, nd * sizeof(DDraw), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_first_tri.p, st2 + nd * sizeof(DDraw), (nd + 1) * 4, hipMemcpyHostToDevice, c->stream));
     }
 
-    // ---- opaque shading + skybox
-    const bool have_blend = !blended.empty();
-    void* color_target = c->d_hdr.p;
-    if (S == 4 && have_blend) { HIP_TRY(c->d_samples.ensure(n * 4 * 8)); color_target = c->d_samples.p; }
-    HIP_TRY(c->d_shade_tris.ensure(std::max<size_t>(n_main_tris, 1) * sizeof(DShadeTri)));
-    launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>(), c->d_first_tri.as<uint32_t>(),
-                       (uint32_t)c->main_draws.size(), n_main_tris, c->d_recs.as<DTriRec>() + main_first_instance, c->d_shade_tris.as<DShadeTri>());
+    // ---- opaque shading + skybox. d_draws / d_first_tri still hold the whole batch; a view's draws are a slice.
+    if (S == 4 && have_blend) HIP_TRY(c->d_samples.ensure(n * 4 * 8));
+    HIP_TRY(c->d_shade_tris.ensure(std::max<size_t>((size_t)n_main_tris + n_blend_tris, 1) * sizeof(DShadeTri)));
+    DShadeTri* tris_main = c->d_shade_tris.as<DShadeTri>();
+    DShadeTri* tris_blend = tris_main + n_main_tris;
+    launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_main_draw, c->d_first_tri.as<uint32_t>() + first_main_draw,
+                       (uint32_t)n_main_draws, n_main_tris, c->d_recs.as<DTriRec>() + main_first_instance, tris_main);
+    if (have_blend)
+        launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_blend_draw,
+                           c->d_first_tri.as<uint32_t>() + first_blend_draw, (uint32_t)n_blend_draws, n_blend_tris,
+                           c->d_recs.as<DTriRec>() + blend_first_instance, tris_blend);
     HIP_TRY(hipEventRecord(c->ev[6], c->stream));
-    launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_shade_tris.as<DShadeTri>(), c->d_depth.as<float>(),
-                        c->d_vis.as<uint32_t>(), c->d_hdr.p, (S == 4 && have_blend) ? c->d_samples.p : nullptr, W, H);
+    launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
+                        (S == 4 && have_blend) ? c->d_samples.p : nullptr, c->d_tile_start.as<uint32_t>() + blend_tile_base,
+                        c->d_tile_end.as<uint32_t>() + blend_tile_base, W, H);
     HIP_TRY(hipEventRecord(c->ev[7], c->stream));
     HIP_TRY(hipGetLastError());
 
-    // ---- blended draws, back to front
+    // ---- blended draws, back to front; resolves its tiles into hdr
     if (have_blend) {
-        HIP_TRY(hipStreamSynchronize(c->stream));  // d_draws / staging are about to be reused by the blend batch
-        Batch bb;
-        bb.views.push_back(make_view(c->d_depth.as<float>(), nullptr, W, H, S, 2, 1));
-        bb.draws = blended;
-        uint32_t n_tiles = 0;
-        int cur = 0;
-        RDR_TRY(bin_batch(c, bb, &n_tiles, &cur));
-        c->stats.views -= 1;  // the blended draws belong to the main view, already counted
-        const DDraw& last = bb.draws.back();
-        const uint32_t n_blend_tris = last.first_tri_id + c->prims[last.prim].tri_count;
-        HIP_TRY(c->d_shade_tris.ensure((size_t)n_blend_tris * sizeof(DShadeTri)));  // the opaque pass is done with it (stream order)
-        launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>(), c->d_first_tri.as<uint32_t>(),
-                           (uint32_t)bb.draws.size(), n_blend_tris, c->d_recs.as<DTriRec>(), c->d_shade_tris.as<DShadeTri>());
-        launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>(), c->d_shade_tris.as<DShadeTri>(),
+        const uint32_t n_tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
+        launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
                             c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
-                            c->d_tile_end.as<uint32_t>(), n_tiles, color_target);
-        if (S == 4) launch_resolve4(c->stream, c->d_samples.p, c->d_hdr.p, (uint32_t)n);
+                            c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p);
         HIP_TRY(hipGetLastError());
     }
 

@@ -56,7 +56,7 @@ struct DView {
     uint32_t cull;       // 0 none, 1 front, 2 back
     uint32_t tiles_x, tiles_y;
     uint32_t tile_base;  // first global tile id of this view
-    uint32_t load;       // 0: clear depth to 1.0 first, 1: keep what the target holds
+    uint32_t load;       // 0: clear depth to 1.0 first, 1: keep what the target holds, 2: binned only (the blended pass rasterises it)
 };
 
 // One draw = one primitive seen from one view.
