@@ -14,6 +14,11 @@
 
 #define RDR_DEV __device__ __forceinline__
 
+// Pointers that kernels find inside structures in memory are generic to the compiler, and loads through them
+// become flat_load (which also ties up the LDS counter). Everything such a pointer can point at here is HBM.
+#define RDR_GLOBAL __attribute__((address_space(1)))
+template <class T> RDR_DEV const RDR_GLOBAL T* as_global(const T* p) { return (const RDR_GLOBAL T*)p; }
+
 struct F3 { float x, y, z; };
 struct F4 { float x, y, z, w; };
 
@@ -146,7 +151,7 @@ RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float
     const int face = cube_face_fast(dx, dy, dz, s, t);
     const uint32_t rr = cube.res >> level;
     const int r = (int)(rr ? rr : 1u);
-    const uint32_t* px = cube.texels + cube.level_offset[level] + (size_t)face * r * r;
+    const RDR_GLOBAL uint32_t* px = as_global(cube.texels) + cube.level_offset[level] + (size_t)face * r * r;
     const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
@@ -182,20 +187,47 @@ RDR_DEV int wrap_index(int i, int n, uint32_t mode) {
 }
 // `srgb` points at the 256-entry sRGB decode table (LDS copy in the hot kernels).
 // UNORM channels decode as byte * (1/255). MASK selects the channels the caller
-// reads (bit k = channel k); the others are left untouched.
+// reads (bit k = channel k); the others are left untouched. `table` is the
+// global DTexture table, read only for images whose level offsets are not
+// arithmetic (not a power-of-two square).
+RDR_DEV uint32_t tex_level_offset(const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level) {
+    const uint32_t flags = t.info >> 5;
+    if (flags & RDR_TEXD_POW2_SQUARE) {
+        // sum_{i<level} 4^(n-i) = (4^(n+1) - 4^(n-level+1)) / 3 with w = h = 2^n
+        const uint32_t n = 31u - (uint32_t)__clz((int)(t.wh & 0xFFFFu));
+        return ((4u << (2u * n)) - (4u << (2u * (n - level)))) / 3u;
+    }
+    return as_global(table)[t.info >> 16].level_offset[level];
+}
+// Texel pair (i0, i0 + 1) and weight along one axis. REPEAT works on the fractional part of the coordinate, which
+// needs no integer modulo; the weight differs from the unwrapped formula only by rounding, and bilinear filtering
+// is continuous across texel boundaries.
+RDR_DEV void tex_axis(float coord, int n, uint32_t mode, int& i0, int& i1, float& a) {
+    if (mode == 0u) coord -= floorf(coord);
+    const float tc = coord * (float)n - 0.5f;
+    const float fc = floorf(tc);
+    a = tc - fc;
+    if (mode == 0u) {
+        const int i = (int)fc;  // in [-1, n-1]
+        i0 = i < 0 ? n - 1 : i;
+        i1 = i + 1 >= n ? 0 : i + 1;
+    } else {
+        i0 = wrap_index((int)fc, n, mode);
+        i1 = wrap_index((int)fc + 1, n, mode);
+    }
+}
 template <int MASK>
-RDR_DEV void tex_bilinear(const float* srgb, const DTexture& t, uint32_t level, float u, float v, float out[4]) {
-    const uint32_t ww = t.w >> level, hh = t.h >> level;
+RDR_DEV void tex_bilinear(const float* srgb, const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level, float u, float v, float out[4]) {
+    const uint32_t ww = (t.wh & 0xFFFFu) >> level, hh = (t.wh >> 16) >> level;
     const int w = (int)(ww ? ww : 1u), h = (int)(hh ? hh : 1u);
-    const uint32_t* px = (const uint32_t*)t.base + t.level_offset[level];
-    const float tu = u * (float)w - 0.5f, tv = v * (float)h - 0.5f;
-    const float fu = floorf(tu), fv = floorf(tv);
-    const float a = tu - fu, b = tv - fv;
-    const uint32_t wu = (t.flags >> 4) & 3u, wv = (t.flags >> 8) & 3u;
-    const int i0 = wrap_index((int)fu, w, wu), i1 = wrap_index((int)fu + 1, w, wu);
-    const int j0 = wrap_index((int)fv, h, wv), j1 = wrap_index((int)fv + 1, h, wv);
+    const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base) + tex_level_offset(t, table, level);
+    const uint32_t flags = t.info >> 5;
+    int i0, i1, j0, j1;
+    float a, b;
+    tex_axis(u, w, (flags >> 2) & 3u, i0, i1, a);
+    tex_axis(v, h, (flags >> 4) & 3u, j0, j1, b);
     const uint32_t q00 = px[j0 * w + i0], q10 = px[j0 * w + i1], q01 = px[j1 * w + i0], q11 = px[j1 * w + i1];
-    const bool is_srgb = (t.flags & 1u) != 0u;
+    const bool is_srgb = (flags & RDR_TEXD_SRGB) != 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (!(MASK & (1 << k))) continue;
@@ -209,20 +241,25 @@ RDR_DEV void tex_bilinear(const float* srgb, const DTexture& t, uint32_t level, 
 }
 // texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2)
 template <int MASK>
-RDR_DEV void tex_sample(const float* srgb, const DTexture& t, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4]) {
+RDR_DEV void tex_sample(const float* srgb, const DTexDesc& t, const DTexture* __restrict__ table, float u, float v, float dudx, float dvdx,
+                        float dudy, float dvdy, float out[4]) {
+    const uint32_t levels = t.info & 31u;
     float lambda = 0.0f;
-    if (t.levels > 1u) {
-        const float ax = dudx * (float)t.w, ay = dvdx * (float)t.h, bx = dudy * (float)t.w, by = dvdy * (float)t.h;
+    if (levels > 1u) {
+        const float fw = (float)(t.wh & 0xFFFFu), fh = (float)(t.wh >> 16);
+        const float ax = dudx * fw, ay = dvdx * fh, bx = dudy * fw, by = dvdy * fh;
         const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
-        if (rho2 > 1.0f) lambda = fminf(0.5f * __log2f(rho2), (float)(t.levels - 1u));
+        if (rho2 > 1.0f) lambda = fminf(0.5f * __log2f(rho2), (float)(levels - 1u));
     }
-    if (!(lambda > 0.0f)) { tex_bilinear<MASK>(srgb, t, 0, u, v, out); return; }
+    // one branch for the whole wave: minified anywhere -> two levels everywhere (a magnified lane blends level 0
+    // with weight 1, which is exact)
+    if (!__any(lambda > 0.0f)) { tex_bilinear<MASK>(srgb, t, table, 0, u, v, out); return; }
     const float fl = floorf(lambda);
-    const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, t.levels - 1u);
+    const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, levels - 1u);
     const float f = lambda - fl;
     float c0[4], c1[4];
-    tex_bilinear<MASK>(srgb, t, l0, u, v, c0);
-    tex_bilinear<MASK>(srgb, t, l1, u, v, c1);
+    tex_bilinear<MASK>(srgb, t, table, l0, u, v, c0);
+    tex_bilinear<MASK>(srgb, t, table, l1, u, v, c1);
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (MASK & (1 << k)) out[k] = fmaf(f, c1[k] - c0[k], c0[k]);

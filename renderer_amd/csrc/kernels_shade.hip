@@ -38,11 +38,11 @@ RDR_DEV F3 fast_normalize(F3 a) { return a * __builtin_amdgcn_rsqf(dot3(a, a)); 
 RDR_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // sampler2DArrayShadow: LINEAR + compare LESS_OR_EQUAL + CLAMP_TO_BORDER(white) (VulkanRendererShadow.cpp:73)
-RDR_DEV float shadow_fetch(const float* __restrict__ map, int res, int i, int j, float ref) {
+RDR_DEV float shadow_fetch(const RDR_GLOBAL float* __restrict__ map, int res, int i, int j, float ref) {
     const float d = (i < 0 || j < 0 || i >= res || j >= res) ? 1.0f : map[(size_t)j * res + i];
     return ref <= d ? 1.0f : 0.0f;
 }
-RDR_DEV float shadow_pcf(const float* __restrict__ map, int res, float s, float t, float ref) {
+RDR_DEV float shadow_pcf(const RDR_GLOBAL float* __restrict__ map, int res, float s, float t, float ref) {
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
@@ -57,7 +57,7 @@ RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, f
     const int res = (int)fr.point_res;
     float s, t;
     const int face = cube_face_fast(rx, ry, rz, s, t);  // the PCF result is continuous in (s,t)
-    const float* map = fr.point_shadow + ((size_t)slot * 6 + face) * res * res;
+    const RDR_GLOBAL float* map = as_global(fr.point_shadow) + ((size_t)slot * 6 + face) * res * res;
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
@@ -67,6 +67,13 @@ RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, f
     const float r01 = ref <= map[j1 * res + i0] ? 1.0f : 0.0f, r11 = ref <= map[j1 * res + i1] ? 1.0f : 0.0f;
     const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
     return (1.0f - b) * top + b * bot;
+}
+
+RDR_DEV DPointLight load_light(const DPointLight* p) {
+    const RDR_GLOBAL DPointLight* g = as_global(p);
+    DPointLight l;
+    l.px = g->px; l.py = g->py; l.pz = g->pz; l.ix = g->ix; l.iy = g->iy; l.iz = g->iz; l.flags = g->flags; l.slot = g->slot;
+    return l;
 }
 
 #define kPI 3.14159274f
@@ -147,9 +154,31 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
         o.uv[k] = a.u; o.uv[3 + k] = a.v;
     }
     o.prim = d.prim;
+    const DMaterial& mt = pr.mat;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o.base_color[k] = mt.base_color[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o.emissive[k] = mt.emissive[k];
+    o.alpha_cutoff = mt.alpha_cutoff;
+    o.metallic = mt.metallic; o.roughness = mt.roughness; o.ao = mt.ao;
+    o.alpha_mode = mt.alpha_mode;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        // defaults of the reference: 1x1 white, and 1x1 (128,128,255,0) for the normal map
+        const uint32_t ti = mt.tex[k] != 0xFFFFFFFFu ? mt.tex[k] : (k == 1 ? fr.tex_normal : fr.tex_white);
+        const DTexture& t = fr.textures[ti];
+        const bool pow2sq = t.w == t.h && (t.w & (t.w - 1u)) == 0u && (t.levels == 1u || (1u << (t.levels - 1u)) == t.w);
+        const uint32_t flags = (t.flags & 1u) | (pow2sq ? RDR_TEXD_POW2_SQUARE : 0u) | (((t.flags >> 4) & 3u) << 2) | (((t.flags >> 8) & 3u) << 4);
+        o.tex[k].base = t.base;
+        o.tex[k].wh = t.w | (t.h << 16);
+        o.tex[k].info = t.levels | (flags << 5) | (ti << 16);
+    }
 }
 
-// pbr.frag at the centre of pixel (px,py) of the triangle whose vertex-stage outputs are in T
+// pbr.frag at the centre of pixel (px,py) of the triangle whose vertex-stage outputs are in T.
+// MASKED = false for the opaque list, which holds no alpha-masked primitive: the cut-off test and its early
+// exit disappear and the five texture fetches can be in flight together.
+template <bool MASKED>
 RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri& T, int px, int py, float out[4]) {
     // ---- perspective-correct barycentrics (double) at (px,py), (px+1,py), (px,py+1)
     const float x0 = fmaf((float)px + 0.5f, fr.inv2W, -1.0f), x1 = fmaf((float)px + 1.5f, fr.inv2W, -1.0f);
@@ -177,22 +206,21 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     const float u0 = interp3(lam[0], T.uv[0], T.uv[1], T.uv[2]), v0 = interp3(lam[0], T.uv[3], T.uv[4], T.uv[5]);
     const float dudx = interp3(lam[1], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdx = interp3(lam[1], T.uv[3], T.uv[4], T.uv[5]) - v0;
     const float dudy = interp3(lam[2], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdy = interp3(lam[2], T.uv[3], T.uv[4], T.uv[5]) - v0;
-    const DPrim& pr = fr.prims[T.prim];
-    const DMaterial& mt = pr.mat;
+    const DShadeTri& mt = T;  // material block and texture descriptors travel with the triangle
 
     // ---- pbr.frag main()
     float t[4];
-    tex_sample<15>(srgb, fr.textures[mt.tex[0] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[0]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<15>(srgb, T.tex[0], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float albedo[4] = {t[0] * mt.base_color[0], t[1] * mt.base_color[1], t[2] * mt.base_color[2], t[3] * mt.base_color[3]};
-    if (mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
-    tex_sample<6>(srgb, fr.textures[mt.tex[2] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[2]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    tex_sample<6>(srgb, T.tex[2], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
     const float roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
-    tex_sample<1>(srgb, fr.textures[mt.tex[3] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[3]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<1>(srgb, T.tex[3], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float ao = t[0] * mt.ao;
-    tex_sample<7>(srgb, fr.textures[mt.tex[4] == 0xFFFFFFFFu ? fr.tex_white : mt.tex[4]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<7>(srgb, T.tex[4], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
     const float emissive[3] = {t[0] * mt.emissive[0], t[1] * mt.emissive[1], t[2] * mt.emissive[2]};
-    tex_sample<7>(srgb, fr.textures[mt.tex[1] == 0xFFFFFFFFu ? fr.tex_normal : mt.tex[1]], u0, v0, dudx, dvdx, dudy, dvdy, t);
+    tex_sample<7>(srgb, T.tex[1], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
     const float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f, nz = t[2] * 2.0f - 1.0f;
     const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
@@ -208,23 +236,38 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     // ---- point lights (pbr.frag:123-160)
     // depth of the cube-face projection (near .1, far 100): (far - far*near/d) / (far - near) = c0 - c1 / d
     const float c0 = 100.0f / (100.0f - 0.1f), c1 = (100.0f * 0.1f) / (100.0f - 0.1f);
-    for (uint32_t li = 0; li < fr.n_lights; li++) {
-        const DPointLight pl = fr.lights[li];
-        const F3 Lv = f3(pl.px, pl.py, pl.pz) - P;
-        const float d2 = dot3(Lv, Lv);  // distance^2
-        // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
-        if (fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2) continue;
-        const float attenuation = fast_rcp(d2);
-        const F3 radiance = f3(pl.ix * attenuation, pl.iy * attenuation, pl.iz * attenuation);
-        if ((pl.flags & 1u) && (pl.flags & 2u)) {
-            const float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
-            const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
-            const float shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, ref);
-            if (shadowTest < 1e-3f) continue;
-            const F3 r = brdf(radiance, Lv * __builtin_amdgcn_rsqf(d2), N, V, alb, roughness, metallic, F0);
-            Lo = Lo + r * shadowTest;
-        } else {
-            Lo = Lo + brdf(radiance, Lv, N, V, alb, roughness, metallic, F0);  // L not normalised (pbr.frag:158)
+    // Four lights at a time, in two phases: first the light vectors and the shadow-map lookups of all four (their
+    // loads overlap), then the BRDFs. Whether a light casts shadows is uniform, so that branch costs nothing.
+    for (uint32_t base = 0; base < fr.n_lights; base += 4u) {
+        F3 Lv[4];
+        float d2[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            sh[j] = 0.0f; d2[j] = 1.0f; Lv[j] = f3(0.0f, 0.0f, 0.0f);
+            if (base + j >= fr.n_lights) continue;
+            const DPointLight pl = load_light(fr.lights + (base + j));
+            Lv[j] = f3(pl.px, pl.py, pl.pz) - P;
+            d2[j] = dot3(Lv[j], Lv[j]);  // distance^2
+            sh[j] = 1.0f;
+            if ((pl.flags & 1u) && (pl.flags & 2u)) {
+                const float lightDepth = fmaxf(fabsf(Lv[j].x), fmaxf(fabsf(Lv[j].y), fabsf(Lv[j].z))) - 0.05f;
+                const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
+                const float shadowTest = shadow_cube(fr, pl.slot, -Lv[j].x, -Lv[j].y, -Lv[j].z, ref);
+                sh[j] = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (base + j >= fr.n_lights) continue;
+            const DPointLight pl = load_light(fr.lights + (base + j));
+            // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
+            if (fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2[j] || sh[j] == 0.0f) continue;
+            const float attenuation = fast_rcp(d2[j]);
+            const F3 radiance = f3(pl.ix * attenuation, pl.iy * attenuation, pl.iz * attenuation);
+            // a light with a shadow map uses the normalised direction, one without does not (pbr.frag:154-158)
+            const float ls = ((pl.flags & 1u) && (pl.flags & 2u)) ? __builtin_amdgcn_rsqf(d2[j]) : 1.0f;
+            const F3 r = brdf(radiance, Lv[j] * ls, N, V, alb, roughness, metallic, F0);
+            Lo = Lo + r * sh[j];
         }
     }
 
@@ -240,7 +283,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
             if (fminf(ls0, ls1) > 1e-2f && fmaxf(ls0, ls1) < 1.0f - 1e-2f) break;
         }
         const int layer = min(split, ncasc - 1);
-        const float shadowTest = shadow_pcf(fr.dir_shadow + (size_t)layer * res * res, res, ls0, ls1, ls2);
+        const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * res * res, res, ls0, ls1, ls2);
         if (shadowTest > 1e-3f) {
             const F3 r = brdf(f3(fr.dir_I[0], fr.dir_I[1], fr.dir_I[2]), f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2]), N, V, alb, roughness, metallic, F0);
             Lo = Lo + r * shadowTest;
@@ -258,12 +301,11 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
         cube_sample_fast(fr.prefiltered, l1, Rv.x, Rv.y, Rv.z, s1);
         {
             const int w = (int)fr.lut_w, h = (int)fr.lut_h;
-            const float lu = NdotV * (float)w - 0.5f, lv = roughness * (float)h - 0.5f;
-            const float fu = floorf(lu), fv = floorf(lv);
-            const float a = lu - fu, b = lv - fv;
-            const int i0 = wrap_index((int)fu, w, 0u), i1 = wrap_index((int)fu + 1, w, 0u);
-            const int j0 = wrap_index((int)fv, h, 0u), j1 = wrap_index((int)fv + 1, h, 0u);
-            const uint32_t* lp = (const uint32_t*)fr.lut;
+            int i0, i1, j0, j1;
+            float a, b;
+            tex_axis(NdotV, w, 0u, i0, i1, a);
+            tex_axis(roughness, h, 0u, j0, j1, b);
+            const RDR_GLOBAL uint32_t* lp = as_global((const uint32_t*)fr.lut);
             const uint32_t q00 = lp[j0 * w + i0], q10 = lp[j0 * w + i1], q01 = lp[j1 * w + i0], q11 = lp[j1 * w + i1];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -289,7 +331,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     out[0] = fminf(Lo.x + emissive[0], 10.0f);
     out[1] = fminf(Lo.y + emissive[1], 10.0f);
     out[2] = fminf(Lo.z + emissive[2], 10.0f);
-    out[3] = mt.alpha_mode == 1 ? 1.0f : albedo[3];
+    out[3] = (MASKED && mt.alpha_mode == 1) ? 1.0f : albedo[3];
 }
 
 RDR_DEV uint32_t find_draw_by_tri(const uint32_t* __restrict__ first_tri, uint32_t n, uint32_t id) {
@@ -323,8 +365,11 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 // hdr, except in tiles whose blended-pass triangle list is not empty
 // (blend_start < blend_end): those keep their four sample colours in
 // `samples_out` for k_raster_blend, which resolves them afterwards.
+#ifndef RDR_SHADE_WAVES
+#define RDR_SHADE_WAVES 4  // waves per SIMD the register allocation is held to (128 VGPRs)
+#endif
 template <int S>
-__global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
+__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
                                                       const float* __restrict__ depth, const uint32_t* __restrict__ vis,
                                                       uint2* __restrict__ hdr, uint2* __restrict__ samples_out,
                                                       const uint32_t* __restrict__ blend_start, const uint32_t* __restrict__ blend_end) {
@@ -387,7 +432,7 @@ __global__ void __launch_bounds__(256) k_shade_opaque(const DFrame* __restrict__
         const int fw = (int)(t >> 6), fl = (int)(t & 63u);
         const int fx = tx * RDR_TILE + (fw & 1) * 8 + (fl & 7), fy = ty * RDR_TILE + (fw >> 1) * 8 + (fl >> 3);
         float c[4];
-        shade_fragment(fr, lds_srgb, tris[id], fx, fy, c);
+        shade_fragment<false>(fr, lds_srgb, tris[id], fx, fy, c);
         lds_frag_col[f] = pack_half4(c[0], c[1], c[2], c[3]);
     }
     __syncthreads();
@@ -486,7 +531,7 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
         for (uint32_t f = (uint32_t)lane; f < n_list; f += 64u) {
             const uint32_t fl = f_meta[f] & 63u;
             float c[4];
-            shade_fragment(fr, lds_srgb, tris[f_id[f]], qx0 + (int)(fl & 7u), qy0 + (int)(fl >> 3), c);
+            shade_fragment<true>(fr, lds_srgb, tris[f_id[f]], qx0 + (int)(fl & 7u), qy0 + (int)(fl >> 3), c);
             f_col[f] = make_float4(c[0], c[1], c[2], c[3]);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

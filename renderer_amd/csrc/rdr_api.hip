@@ -689,6 +689,7 @@ int rdr_load_image(rdr_ctx* c, const void* ptr, size_t size, uint32_t w, uint32_
         default: return fail(c, RDR_ERR_UNSUPPORTED, "load_image: only 8-bit formats are supported");
     }
     if (size < (size_t)w * h * ch) return fail(c, RDR_ERR_INVALID, "load_image: size too small");
+    if (w > 32768u || h > 32768u) return fail(c, RDR_ERR_UNSUPPORTED, "load_image: images larger than 32768 texels on a side are not supported");
     HIP_TRY(hipSetDevice(c->device));
     const uint8_t* s = (const uint8_t*)ptr;
     std::vector<uint8_t> rgba;

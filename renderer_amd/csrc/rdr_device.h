@@ -81,16 +81,34 @@ struct DTriRec {
     uint32_t _pad2[2];
 };  // 128 bytes
 
-// Vertex-stage outputs of one main-view triangle (basic.vert), written once per
-// frame by the shading set-up kernel and read by every fragment of the triangle.
-struct DShadeTri {
+// Compact texture descriptor inside a DShadeTri: everything a fetch needs without another table look-up.
+#define RDR_TEXD_SRGB 1u        // flags bit 0
+#define RDR_TEXD_POW2_SQUARE 2u  // flags bit 1: w == h == 2^n with a complete chain, level offsets are arithmetic
+struct DTexDesc {
+    const uint8_t* base;  // RGBA8 texels, all levels
+    uint32_t wh;          // w | h << 16
+    uint32_t info;        // levels (5 bits) | flags << 5 (srgb, pow2-square, wrap_u << 2, wrap_v << 4) | texture index << 16
+};  // 16 bytes
+
+// Everything the fragments of one triangle share: the vertex-stage outputs
+// (basic.vert), the material block (pbr.frag:21-37) and its five texture
+// descriptors. Written once per frame by the shading set-up kernel; the shading
+// kernels stage the records of the triangles a wave touches in LDS.
+struct alignas(16) DShadeTri {
     double A[3], B[3], C[3];  // homogeneous barycentric planes: l_k(x,y) = A_k x + B_k y + C_k in NDC
     float wp[9];              // world position, component-major: x0 x1 x2 y0 y1 y2 z0 z1 z2
     float nrm[9], tan[9], bit[9];
     float uv[6];              // u0 u1 u2 v0 v1 v2
+    float base_color[4];
+    float emissive[3];
+    float alpha_cutoff;
+    float metallic, roughness, ao;
+    int32_t alpha_mode;
+    DTexDesc tex[5];          // albedo, normal, metalRough, ao, emissive
     uint32_t prim;
     uint32_t _pad[3];
-};  // 256 bytes
+};  // 384 bytes = 24 x 16
+#define RDR_SHADE_TRI_VEC4 24
 
 struct DPointLight {
     float px, py, pz;

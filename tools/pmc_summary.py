@@ -1,16 +1,39 @@
-"""Summarises a rocprofv3 --pmc counter_collection.csv: per kernel name, the mean of each counter per dispatch."""
+"""Summarises rocprofv3 output directories written by tools/profile_gpu.sh.
+
+  python tools/pmc_summary.py gpurun_out/prof_TAG [kernel-name-substring ...]
+
+Per kernel: average duration (kernel-trace stats) and the mean of every PMC counter per dispatch.
+SQ_* cycle counters are in quad-cycles. FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 prints them; FETCH_SIZE
+under-reports wide coalesced streaming reads by 2x on gfx950 (each 128-B request is tallied as 64 B).
+"""
 import csv
+import glob
 import sys
 from collections import defaultdict
 
-path = sys.argv[1]
+root = sys.argv[1]
+only = sys.argv[2:]
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+dur = {}
+for f in glob.glob(root + "/stats/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
 acc = defaultdict(lambda: defaultdict(list))
-for r in csv.DictReader(open(path)):
-    acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-only = sys.argv[2:] 
-for k, cs in acc.items():
+regs = {}
+for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        regs[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"])
+for k in sorted(dur, key=lambda k: -dur[k][2]):
     if only and not any(o in k for o in only):
         continue
-    print(k[:90])
-    for c, v in sorted(cs.items()):
-        print("   %-28s n=%-4d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+    calls, avg, pct = dur[k]
+    print(f"{k}: calls {calls}, avg {avg:.1f} us, {pct:.2f} % of GPU time; vgpr/sgpr/lds/scratch = {regs.get(k)}")
+    for c, v in sorted(acc.get(k, {}).items()):
+        print("   %-24s n=%-4d mean=%.5g" % (c, len(v), sum(v) / len(v)))
