@@ -183,6 +183,30 @@ static inline quat quat_look_at(vec3 dir, vec3 up) {
     return q;
 }
 
+// glm::mat4_cast
+static inline mat4 quat_to_mat4(quat q) {
+    const float qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z, qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z;
+    const float qwx = q.w * q.x, qwy = q.w * q.y, qwz = q.w * q.z;
+    mat4 r = mat_identity();
+    r.at(0, 0) = 1.0f - 2.0f * (qyy + qzz); r.at(0, 1) = 2.0f * (qxy + qwz);        r.at(0, 2) = 2.0f * (qxz - qwy);
+    r.at(1, 0) = 2.0f * (qxy - qwz);        r.at(1, 1) = 1.0f - 2.0f * (qxx + qzz); r.at(1, 2) = 2.0f * (qyz + qwx);
+    r.at(2, 0) = 2.0f * (qxz + qwy);        r.at(2, 1) = 2.0f * (qyz - qwx);        r.at(2, 2) = 1.0f - 2.0f * (qxx + qyy);
+    return r;
+}
+// glm::quat(eulerAngles): pitch (x), yaw (y), roll (z)
+static inline quat quat_from_euler(vec3 e) {
+    const float cx = cosf(e.x * 0.5f), cy = cosf(e.y * 0.5f), cz = cosf(e.z * 0.5f);
+    const float sx = sinf(e.x * 0.5f), sy = sinf(e.y * 0.5f), sz = sinf(e.z * 0.5f);
+    quat q;
+    q.w = cx * cy * cz + sx * sy * sz;
+    q.x = sx * cy * cz - cx * sy * sz;
+    q.y = cx * sy * cz + sx * cy * sz;
+    q.z = cx * cy * sz - sx * sy * cz;
+    return q;
+}
+// translate(t) * mat4_cast(r) * scale(s): the local matrix of a node (Renderer/Node.cpp:11)
+static inline mat4 mat_trs(vec3 t, quat r, vec3 s) { return mat_mul(mat_mul(mat_translate(t), quat_to_mat4(r)), mat_scale(s)); }
+
 // Camera of the reference (Renderer/Camera.h:61-82): state + crop matrix.
 struct Camera {
     int type;  // 0 perspective, 1 orthographic

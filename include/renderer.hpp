@@ -1,0 +1,545 @@
+// C++ façade over the C ABI of rdr.h: the reference's own scene API
+// (Camera, Node, Mesh/MeshPrimitive, PointLight, DirectionalLight, Object,
+// handles, RendererSettings) and the public surface of its renderer class
+// (Renderer/VulkanRenderer.h:94-110), header-only, C++17, no dependencies
+// beyond rdr.h and rdr_math.h.
+//
+// A host program written against the reference keeps its scene code; the
+// differences are the ones a head-less compute node forces:
+//   - the window argument of the constructor becomes (width, height, device);
+//   - there is no swap chain: renderFrame() returns the finished RGBA8 image
+//     (start() still spawns a free-running render thread as in the reference,
+//     VulkanRenderer.cpp:495-498, and keeps the latest frame);
+//   - glm types become the small rdr:: structs of rdr_math.h (same layout:
+//     column-major mat4, (w,x,y,z) quaternion);
+//   - the material of a primitive, which the reference's half-refactored
+//     Mesh.h no longer carries (PBRInfo/AlphaInfo are used at main.cpp:162-165
+//     but defined nowhere), is a member of MeshPrimitive.
+//
+// Every entry point is reached through RDR_ABI(name), which pastes
+// RDR_ABI_PREFIX (default rdr_) in front of the name, so the same façade can
+// be compiled against any library exporting the ABI under another prefix.
+#pragma once
+
+#include <array>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "rdr.h"
+#include "rdr_math.h"
+
+#ifndef RDR_ABI_PREFIX
+#define RDR_ABI_PREFIX rdr_
+#endif
+#define RDR_ABI_CAT2(a, b) a##b
+#define RDR_ABI_CAT(a, b) RDR_ABI_CAT2(a, b)
+#define RDR_ABI(name) RDR_ABI_CAT(RDR_ABI_PREFIX, name)
+
+extern "C" {
+// the subset of rdr.h the façade calls, declared under the chosen prefix
+int RDR_ABI(create)(const rdr_settings*, uint32_t, uint32_t, int, rdr_ctx**);
+void RDR_ABI(destroy)(rdr_ctx*);
+const char* RDR_ABI(last_error)(const rdr_ctx*);
+int RDR_ABI(load_buffer)(rdr_ctx*, const void*, size_t, uint32_t*);
+int RDR_ABI(load_image)(rdr_ctx*, const void*, size_t, uint32_t, uint32_t, int, uint32_t, uint32_t*);
+int RDR_ABI(make_texture)(rdr_ctx*, uint32_t, const rdr_sampler*, uint32_t*);
+int RDR_ABI(add_mesh)(rdr_ctx*, const rdr_primitive_desc*, uint32_t, const float*, int, uint32_t*);
+int RDR_ABI(set_mesh_transform)(rdr_ctx*, uint32_t, const float*);
+int RDR_ABI(set_lights)(rdr_ctx*, const rdr_point_light*, uint32_t, const rdr_directional_light*);
+int RDR_ABI(set_environment_map)(rdr_ctx*, const float* const*, uint32_t, uint32_t);
+int RDR_ABI(set_brdf_lut)(rdr_ctx*, const uint8_t*, uint32_t, uint32_t, uint32_t);
+int RDR_ABI(set_camera)(rdr_ctx*, const rdr_camera*);
+int RDR_ABI(set_exposure_bias)(rdr_ctx*, float, float);
+int RDR_ABI(render_frame)(rdr_ctx*, const rdr_frame_params*, uint8_t*, int, float*);
+int RDR_ABI(get_frame_stats)(rdr_ctx*, rdr_frame_stats*);
+}
+
+namespace hiprenderer {
+
+using rdr::mat4;
+using rdr::quat;
+using rdr::vec3;
+using rdr::vec4;
+struct vec2 { float x, y; };
+
+// ---- Handle.h / Buffer.h / Image.h / Texture.h ------------------------------
+template <class keyT, int uniqueID> class Handle {
+    keyT m_key = static_cast<keyT>(~keyT());
+public:
+    Handle() = default;
+    explicit Handle(keyT key) : m_key(key) {}
+    using key_type = keyT;
+    explicit operator keyT() const { return m_key; }
+    bool operator==(const Handle& o) const { return m_key == o.m_key; }
+    bool operator!=(const Handle& o) const { return m_key != o.m_key; }
+    bool operator<(const Handle& o) const { return m_key < o.m_key; }
+    bool operator>(const Handle& o) const { return m_key > o.m_key; }
+    bool isValid() const { return m_key != static_cast<keyT>(~keyT()); }
+};
+typedef Handle<uint32_t, 0> Buffer;
+typedef Handle<uint32_t, 1> Image;
+typedef Handle<uint32_t, 2> Texture;
+
+enum class ImageFormat {  // Image.h:5-14, same values as rdr_image_format
+    eR8G8B8Unorm, eR8G8B8Srgb, eR8G8B8A8Unorm, eR8G8B8A8Srgb, eR16G16B16Sfloat, eR16G16B16A16Sfloat, eR32G32B32Sfloat, eR32G32B32A32Sfloat,
+};
+
+// Sampler.h is missing from the reference tree; these are the fields VulkanRenderer::makeTexture reads
+// (VulkanRenderer.cpp:363-385).
+enum class SamplerFilter { eNearest, eLinear };
+enum class SamplerWrap { eRepeat, eMirroredRepeat, eClampToEdge };
+struct Sampler {
+    SamplerFilter magFilter = SamplerFilter::eLinear, minFilter = SamplerFilter::eLinear, mipmapFilter = SamplerFilter::eLinear;
+    SamplerWrap wrapU = SamplerWrap::eRepeat, wrapV = SamplerWrap::eRepeat;
+};
+
+// ---- Camera.h -----------------------------------------------------------------
+class Camera {
+public:
+    enum class CameraType { ePerspective, eOrthographic };
+    Camera() = default;
+    // the reference's copy drops the crop matrix (Camera.cpp:3-41); kept
+    Camera(const Camera& o) { copyFrom(o); }
+    Camera& operator=(const Camera& o) { if (this != &o) copyFrom(o); return *this; }
+
+    static Camera Perspective(vec3 position, vec3 eulerRotation, float near_, float far_, float vfov, float aspectRatio) {
+        Camera c; c.cameraType = CameraType::ePerspective; c._position = position; c._eulerRotation = eulerRotation;
+        c._near = near_; c._far = far_; c._fovOrHeight = vfov; c._aspectRatio = aspectRatio; return c;
+    }
+    static Camera Ortographic(vec3 position, vec3 eulerRotation, float near_, float far_, float height, float aspectRatio) {
+        Camera c; c.cameraType = CameraType::eOrthographic; c._position = position; c._eulerRotation = eulerRotation;
+        c._near = near_; c._far = far_; c._fovOrHeight = height; c._aspectRatio = aspectRatio; return c;
+    }
+
+    vec3 position() const { std::lock_guard<std::mutex> g(mutex); return _position; }
+    vec3 eulerRotation() const { std::lock_guard<std::mutex> g(mutex); return _eulerRotation; }
+    mat4 viewMatrix() const { std::lock_guard<std::mutex> g(mutex); return state().view(); }
+    mat4 viewProjMatrix() const { std::lock_guard<std::mutex> g(mutex); return state().view_proj(); }
+    std::tuple<vec3, mat4> positionAndMatrix() const { std::lock_guard<std::mutex> g(mutex); return {_position, state().view_proj()}; }
+
+    void setPosition(vec3 p) { std::lock_guard<std::mutex> g(mutex); _position = p; }
+    // translation is given in camera space (Camera.cpp:104-109)
+    void move(vec3 t) {
+        std::lock_guard<std::mutex> g(mutex);
+        const mat4 inv = rdr::mat_inverse(state().view());
+        const vec3 w = rdr::make3(inv.at(0, 0) * t.x + inv.at(1, 0) * t.y + inv.at(2, 0) * t.z,
+                                  inv.at(0, 1) * t.x + inv.at(1, 1) * t.y + inv.at(2, 1) * t.z,
+                                  inv.at(0, 2) * t.x + inv.at(1, 2) * t.y + inv.at(2, 2) * t.z);
+        _position = rdr::add(_position, w);
+    }
+    void pan(vec2 direction) { move(rdr::make3(direction.x, direction.y, 0.0f)); }
+    void dolly(float distance) { move(rdr::make3(0.0f, 0.0f, -distance)); }
+    void tilt(vec2 yawPitch) { std::lock_guard<std::mutex> g(mutex); _eulerRotation = rdr::add(_eulerRotation, rdr::make3(yawPitch.y, yawPitch.x, 0.0f)); }
+    void setEulerRotation(vec3 e) { std::lock_guard<std::mutex> g(mutex); _eulerRotation = e; }
+
+    float near() const { return _near; }
+    float far() const { return _far; }
+    float vfov() const { return _fovOrHeight; }
+    float hfov() const { return _aspectRatio * _fovOrHeight; }  // sic, Camera.cpp:179-181
+    float aspectRatio() const { return _aspectRatio; }
+    CameraType type() const { return cameraType; }
+    void setNear(float n) { std::lock_guard<std::mutex> g(mutex); _near = n; }
+    void setFar(float f) { std::lock_guard<std::mutex> g(mutex); _far = f; }
+    void setVFov(float fov) { std::lock_guard<std::mutex> g(mutex); _fovOrHeight = fov; }
+    void setAspectRatio(float ar) { std::lock_guard<std::mutex> g(mutex); _aspectRatio = ar; }
+    void setCropMatrix(mat4 m) { std::lock_guard<std::mutex> g(mutex); _cropMatrix = m; }
+    void clearCropMatrix() { std::lock_guard<std::mutex> g(mutex); _cropMatrix = rdr::mat_identity(); }
+
+    // Camera::getFrustumVertices (Camera.cpp:218-242): the 8 NDC corners through inverse(viewProj)
+    std::array<vec3, 8> getFrustumVertices() const {
+        static const float ndc[8][3] = {{-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1}};
+        const mat4 inv = rdr::mat_inverse(viewProjMatrix());
+        std::array<vec3, 8> out;
+        for (int k = 0; k < 8; k++) {
+            const vec4 h = rdr::mat_mul_vec(inv, vec4{ndc[k][0], ndc[k][1], ndc[k][2], 1.0f});
+            out[k] = rdr::make3(h.x / h.w, h.y / h.w, h.z / h.w);
+        }
+        return out;
+    }
+
+    rdr_camera toAbi() const {
+        std::lock_guard<std::mutex> g(mutex);
+        rdr_camera c;
+        c.type = cameraType == CameraType::ePerspective ? RDR_CAMERA_PERSPECTIVE : RDR_CAMERA_ORTHOGRAPHIC;
+        c.position[0] = _position.x; c.position[1] = _position.y; c.position[2] = _position.z;
+        c.euler[0] = _eulerRotation.x; c.euler[1] = _eulerRotation.y; c.euler[2] = _eulerRotation.z;
+        c.near_plane = _near; c.far_plane = _far; c.fov_or_height = _fovOrHeight; c.aspect_ratio = _aspectRatio;
+        return c;
+    }
+
+private:
+    void copyFrom(const Camera& o) {
+        std::lock_guard<std::mutex> g(o.mutex);
+        _position = o._position; _eulerRotation = o._eulerRotation; cameraType = o.cameraType;
+        _near = o._near; _far = o._far; _fovOrHeight = o._fovOrHeight; _aspectRatio = o._aspectRatio;
+        _cropMatrix = rdr::mat_identity();
+    }
+    rdr::Camera state() const {
+        rdr::Camera s;
+        s.type = cameraType == CameraType::ePerspective ? 0 : 1;
+        s.position = _position; s.euler = _eulerRotation;
+        s.near_plane = _near; s.far_plane = _far; s.fov_or_height = _fovOrHeight; s.aspect = _aspectRatio;
+        s.crop = _cropMatrix;
+        return s;
+    }
+    mutable std::mutex mutex;
+    vec3 _position{0, 0, 0}, _eulerRotation{0, 0, 0};
+    mat4 _cropMatrix = rdr::mat_identity();
+    CameraType cameraType = CameraType::ePerspective;
+    float _near = 0.1f, _far = 100.0f, _fovOrHeight = 35.0f, _aspectRatio = 16.0f / 9.0f;
+};
+
+// ---- Node.h / Node.cpp ----------------------------------------------------------
+class Node {
+public:
+    Node(const vec3& translation, const quat& rotation, const vec3& scale, const std::vector<std::shared_ptr<Node>>& children)
+        : children(children), _translation(translation), _rotation(rotation), _scale(scale) { recalculateModel(rdr::mat_identity()); }
+    // the reference decomposes the matrix into TRS (Node.h:25-36); the matrix itself stays the local transform here
+    Node(const mat4& matrix, const std::vector<std::shared_ptr<Node>>& children) : children(children), _modelLocal(matrix), _model(matrix) {
+        modelDirty = false; hasMatrix = true;
+        for (auto& c : this->children) c->recalculateModel(matrix);
+    }
+    vec3 translation() const { return _translation; }
+    quat rotation() const { return _rotation; }
+    vec3 scale() const { return _scale; }
+    void setTranslation(vec3 t) { _translation = t; modelDirty = true; hasMatrix = false; }
+    void setRotation(quat r) { _rotation = r; modelDirty = true; hasMatrix = false; }
+    void setScale(vec3 s) { _scale = s; modelDirty = true; hasMatrix = false; }
+    void setTransform(vec3 t, quat r, vec3 s) { _translation = t; _rotation = r; _scale = s; modelDirty = true; hasMatrix = false; }
+    mat4 modelMatrix() const { return _model; }
+    // Node.cpp:9-19
+    void recalculateModel(const mat4& parentModel) {
+        if (modelDirty && !hasMatrix) _modelLocal = rdr::mat_trs(_translation, _rotation, _scale);
+        modelDirty = false;
+        _model = rdr::mat_mul(parentModel, _modelLocal);
+        for (auto& c : children) c->recalculateModel(_model);
+    }
+    bool isStatic() const { return _isStatic; }
+    void setStatic(bool s) { _isStatic = s; for (auto& c : children) c->setStatic(s); }  // Node.cpp:65-75 without animation tracks
+    const std::vector<std::shared_ptr<Node>>& childNodes() const { return children; }
+
+private:
+    std::vector<std::shared_ptr<Node>> children;
+    vec3 _translation{0, 0, 0};
+    quat _rotation{1, 0, 0, 0};
+    vec3 _scale{1, 1, 1};
+    bool _isStatic = true, modelDirty = true, hasMatrix = false;
+    mat4 _modelLocal = rdr::mat_identity(), _model = rdr::mat_identity();
+};
+
+// ---- Mesh.h ---------------------------------------------------------------------
+enum class AttributeValueType { eInt8, eInt16, eInt32, eInt64, eUint8, eUint16, eUint32, eUint64, eHalf, eFloat, eDouble };
+enum class AttributeContainerType { eScalar, eVec2, eVec3, eVec4 };
+enum class MeshPrimitiveMode { ePoints, eLines, eLineLoop, eLineStrip, eTriangles, eTriangleStrip, eTriangleFan };
+
+struct VertexAttributeDescription {
+    std::string attributeName;  // "POSITION", "NORMAL", "TANGENT", "TEXCOORD_0" (glTF semantics, main.cpp:367-400)
+    Buffer buffer;
+    size_t offset = 0;
+    int32_t stride = 0;
+    size_t count = 0;
+    AttributeContainerType containerType = AttributeContainerType::eVec3;
+    AttributeValueType valueType = AttributeValueType::eFloat;
+};
+struct IndexBufferDescription {
+    Buffer buffer;
+    size_t offset = 0;
+    int32_t stride = 0;
+    size_t count = 0;
+    AttributeValueType indexType = AttributeValueType::eUint32;
+};
+
+enum class AlphaMode { eOpaque, eMask, eBlend };
+struct PBRInfo {  // main.cpp:162, pbr.frag:21-30
+    float baseColorFactor[4] = {1, 1, 1, 1};
+    float emissiveFactor[4] = {0, 0, 0, 0};
+    float normalScale = 1.0f, metallicFactor = 1.0f, roughnessFactor = 1.0f, aoFactor = 1.0f;
+};
+struct AlphaInfo { AlphaMode alphaMode = AlphaMode::eOpaque; float alphaCutoff = 0.5f; };
+struct Material {
+    PBRInfo materialInfo;
+    AlphaInfo alphaInfo;
+    Texture albedoTexture, normalTexture, metalRoughnessTexture, aoTexture, emissiveTexture;  // invalid handle = the reference's defaults
+};
+
+class MeshPrimitive {
+    std::vector<VertexAttributeDescription> m_vertexBufferDescription;
+    bool m_isIndexed = false;
+    IndexBufferDescription m_indexBufferDescription;
+    vec3 m_bbMin{0, 0, 0}, m_bbMax{0, 0, 0};
+    MeshPrimitiveMode m_mode = MeshPrimitiveMode::eTriangles;
+public:
+    Material material;
+    MeshPrimitive() = default;
+    MeshPrimitive(std::vector<VertexAttributeDescription> v, vec3 bbMin, vec3 bbMax, MeshPrimitiveMode mode)
+        : m_vertexBufferDescription(std::move(v)), m_bbMin(bbMin), m_bbMax(bbMax), m_mode(mode) {}
+    MeshPrimitive(std::vector<VertexAttributeDescription> v, IndexBufferDescription i, vec3 bbMin, vec3 bbMax, MeshPrimitiveMode mode)
+        : m_vertexBufferDescription(std::move(v)), m_isIndexed(true), m_indexBufferDescription(i), m_bbMin(bbMin), m_bbMax(bbMax), m_mode(mode) {}
+    const std::vector<VertexAttributeDescription>& vertexBufferDescription() const { return m_vertexBufferDescription; }
+    const IndexBufferDescription& indexBufferDescription() const { return m_indexBufferDescription; }
+    bool isIndexed() const { return m_isIndexed; }
+    vec3 bbMin() const { return m_bbMin; }
+    vec3 bbMax() const { return m_bbMax; }
+    MeshPrimitiveMode mode() const { return m_mode; }
+};
+class Mesh {
+public:
+    std::vector<MeshPrimitive> primitives;
+    std::shared_ptr<Node> node;
+    Mesh(std::vector<MeshPrimitive> p, std::shared_ptr<Node> n) : primitives(std::move(p)), node(std::move(n)) {}
+};
+
+// ---- PointLight.h / DirectionalLight.h -------------------------------------------
+enum class PointLightFlagBits : uint8_t { eNone = 0, eCastShadows = 1, eHasShadowMap = 2, eStaticShadowMapRendered = 4 };
+class PointLight {
+public:
+    vec3 point, intensity;
+    uint8_t flags;
+    uint16_t shadowMapIndex;
+    PointLight(vec3 point, vec3 intensity, bool castShadows)
+        : point(point), intensity(intensity), flags(castShadows ? (uint8_t)PointLightFlagBits::eCastShadows : 0), shadowMapIndex(0xFFFF) {}
+};
+class DirectionalLight {
+public:
+    vec3 position{0, 100, 0}, intensity{0, 0, 0};
+    quat orientation{1, 0, 0, 0};
+    bool castShadows = true;
+    bool staticShadowMapRendered = false;
+    // DirectionalLight.cpp:3-5
+    Camera lightViewCamera() const { return Camera::Ortographic(position, rdr::quat_euler(orientation), 0.1f, 200.0f, 10.0f, 1.0f); }
+};
+
+// ---- Object.h (unused by the reference's renderer; kept for source compatibility) ---
+class Object {
+public:
+    void setTranslation(vec3 t) { translation = t; transformDirty = true; }
+    void setRotation(vec3 euler) { rotation = rdr::quat_from_euler(euler); transformDirty = true; }
+    void setRotation(quat q) { rotation = q; transformDirty = true; }
+    void setScale(vec3 s) { scale = s; transformDirty = true; }
+    mat4 getTransformMatrix() {
+        if (transformDirty) transform = rdr::mat_trs(translation, rotation, scale);
+        transformDirty = false;
+        return transform;
+    }
+private:
+    vec3 translation{0, 0, 0};
+    quat rotation{1, 0, 0, 0};
+    vec3 scale{1, 1, 1};
+    bool transformDirty = true;
+    mat4 transform = rdr::mat_identity();
+};
+
+// ---- VulkanRenderer.h:28-59 -------------------------------------------------------
+struct TextureInfo {  // one cube face: RGBA32F bytes (main.cpp:47-59)
+    std::vector<uint8_t> data;
+    uint32_t width = 1, height = 1;
+};
+enum class SampleCount : uint32_t { e1 = 1, e4 = 4 };
+struct RendererSettings {
+    bool hdrOutputEnabled = false;
+    bool dynamicShadowsEnabled = true;
+    uint32_t pointShadowMapResolution = 512;
+    uint16_t pointShadowMapCount = 8;
+    uint32_t directionalShadowMapResolution = 2048;
+    uint8_t directionalShadowCascadeLevels = 4;
+    bool vsync = false;
+    float exposureBias = 0.0f;
+    float gamma = 2.2f;
+    SampleCount msaa = SampleCount::e4;
+};
+
+// How exposure is chosen for a frame (see rdr_frame_params in rdr.h)
+struct FrameParams {
+    int exposureMode = 0;  // 0 reference recurrence with deltaTime, 1 given adapted luminance, 2 given exposure
+    float deltaTime = 1.0f / 60.0f, temporalLuminance = 0.25f, exposure = 0.0f;
+};
+
+// ---- the renderer (public surface of VulkanRenderer, VulkanRenderer.h:94-110) -----------
+class Renderer {
+public:
+    Renderer(uint32_t width, uint32_t height, const RendererSettings& s, int device = 0) : _settings(s), _width(width), _height(height) {
+        rdr_settings a;
+        a.hdr_output_enabled = s.hdrOutputEnabled; a.dynamic_shadows_enabled = s.dynamicShadowsEnabled;
+        a.point_shadow_map_resolution = s.pointShadowMapResolution; a.point_shadow_map_count = s.pointShadowMapCount;
+        a.directional_shadow_map_resolution = s.directionalShadowMapResolution;
+        a.directional_shadow_cascade_levels = s.directionalShadowCascadeLevels;
+        a.vsync = s.vsync; a.exposure_bias = s.exposureBias; a.gamma = s.gamma; a.msaa = (uint32_t)s.msaa;
+        const int rc = RDR_ABI(create)(&a, width, height, device, &ctx);
+        if (rc != RDR_OK) throw std::runtime_error("renderer creation failed with status " + std::to_string(rc));
+        _camera = Camera::Perspective(rdr::make3(0, 0, 0), rdr::make3(0, 0, 0), 0.1f, 60.0f, 40.0f * 0.01745329251994329577f,
+                                      (float)width / (float)height);  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
+    }
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+    ~Renderer() {
+        stop();
+        if (ctx) RDR_ABI(destroy)(ctx);
+    }
+
+    // spawns the free-running render thread of the reference (VulkanRenderer.cpp:495-498)
+    void start() {
+        if (running.exchange(true)) return;
+        renderThread = std::thread([this] {
+            while (running.load()) {
+                std::vector<uint8_t> img = renderFrame(FrameParams{});
+                std::lock_guard<std::mutex> g(latestMutex);
+                latest.swap(img);
+                framesRendered++;
+            }
+        });
+    }
+    void stop() {
+        if (!running.exchange(false)) return;
+        if (renderThread.joinable()) renderThread.join();
+    }
+    std::vector<uint8_t> latestFrame(uint64_t* count = nullptr) {
+        std::lock_guard<std::mutex> g(latestMutex);
+        if (count) *count = framesRendered;
+        return latest;
+    }
+
+    void setRootNodes(const std::vector<Node*>& nodes) { rootNodes = nodes; }
+    void setEnvironmentMap(const std::array<TextureInfo, 6>& faces) {
+        const float* ptrs[6];
+        for (int i = 0; i < 6; i++) {
+            if (faces[i].width != faces[0].width || faces[i].height != faces[0].height ||
+                faces[i].data.size() < (size_t)faces[i].width * faces[i].height * 16)
+                throw std::runtime_error("setEnvironmentMap: faces must be RGBA32F images of one size");
+            ptrs[i] = reinterpret_cast<const float*>(faces[i].data.data());
+        }
+        check(RDR_ABI(set_environment_map)(ctx, ptrs, faces[0].width, faces[0].height), "setEnvironmentMap");
+    }
+    // the reference loads textures/ibl_brdf_lut.png itself (VulkanRenderer.cpp:44-45); here the decoded pixels are handed over
+    void setBrdfLut(const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels) {
+        check(RDR_ABI(set_brdf_lut)(ctx, pixels, width, height, channels), "setBrdfLut");
+    }
+    void setLights(const std::vector<PointLight>& pointLights, const DirectionalLight& d) {
+        std::vector<rdr_point_light> pl(pointLights.size());
+        for (size_t i = 0; i < pl.size(); i++) {
+            const PointLight& s = pointLights[i];
+            pl[i] = rdr_point_light{{s.point.x, s.point.y, s.point.z}, {s.intensity.x, s.intensity.y, s.intensity.z},
+                                    (uint32_t)(s.flags & (uint8_t)PointLightFlagBits::eCastShadows)};
+        }
+        const rdr_directional_light dl = {{d.position.x, d.position.y, d.position.z}, {d.intensity.x, d.intensity.y, d.intensity.z},
+                                          {d.orientation.w, d.orientation.x, d.orientation.y, d.orientation.z}};
+        // the cascade splits are fixed from the camera's near/far at this moment (VulkanRendererShadow.cpp:152-175)
+        const rdr_camera cam = _camera.toAbi();
+        check(RDR_ABI(set_camera)(ctx, &cam), "setLights/camera");
+        check(RDR_ABI(set_lights)(ctx, pl.empty() ? nullptr : pl.data(), (uint32_t)pl.size(), &dl), "setLights");
+    }
+    Buffer loadBuffer(const void* ptr, size_t size) {
+        uint32_t id = RDR_INVALID_ID;
+        check(RDR_ABI(load_buffer)(ctx, ptr, size, &id), "loadBuffer");
+        return Buffer(id);
+    }
+    Image loadImage(const void* ptr, size_t size, uint32_t width, uint32_t height, ImageFormat format, uint32_t maxMipLevels = UINT32_MAX) {
+        uint32_t id = RDR_INVALID_ID;
+        check(RDR_ABI(load_image)(ctx, ptr, size, width, height, (int)format, maxMipLevels, &id), "loadImage");
+        return Image(id);
+    }
+    Texture makeTexture(Image image, Sampler sampler) {
+        const rdr_sampler s = {(uint32_t)sampler.magFilter, (uint32_t)sampler.minFilter, (uint32_t)sampler.mipmapFilter,
+                               (uint32_t)sampler.wrapU, (uint32_t)sampler.wrapV};
+        uint32_t id = RDR_INVALID_ID;
+        check(RDR_ABI(make_texture)(ctx, (uint32_t)image, &s, &id), "makeTexture");
+        return Texture(id);
+    }
+    void addMesh(const Mesh& mesh) {
+        std::vector<rdr_primitive_desc> descs(mesh.primitives.size());
+        std::vector<std::vector<rdr_vertex_attribute>> attrs(mesh.primitives.size());
+        for (size_t i = 0; i < descs.size(); i++) {
+            const MeshPrimitive& p = mesh.primitives[i];
+            for (const VertexAttributeDescription& v : p.vertexBufferDescription()) {
+                uint32_t name;
+                if (v.attributeName == "POSITION") name = RDR_ATTR_POSITION;
+                else if (v.attributeName == "NORMAL") name = RDR_ATTR_NORMAL;
+                else if (v.attributeName == "TANGENT") name = RDR_ATTR_TANGENT;
+                else if (v.attributeName == "TEXCOORD_0") name = RDR_ATTR_TEXCOORD_0;
+                else if (v.attributeName == "BITANGENT") name = RDR_ATTR_BITANGENT;
+                else continue;  // attributes the shaders do not read
+                attrs[i].push_back(rdr_vertex_attribute{name, (uint32_t)v.buffer, v.offset, v.stride, (uint32_t)v.containerType, v.count,
+                                                        (uint32_t)v.valueType, 0});
+            }
+            rdr_primitive_desc& d = descs[i];
+            std::memset(&d, 0, sizeof d);
+            d.attributes = attrs[i].data(); d.attribute_count = (uint32_t)attrs[i].size();
+            d.mode = (uint32_t)p.mode();
+            const IndexBufferDescription& ib = p.indexBufferDescription();
+            d.indices = rdr_index_buffer{p.isIndexed() ? (uint32_t)ib.buffer : RDR_INVALID_ID, (uint32_t)ib.indexType, ib.offset, ib.count};
+            const vec3 mn = p.bbMin(), mx = p.bbMax();
+            d.bb_min[0] = mn.x; d.bb_min[1] = mn.y; d.bb_min[2] = mn.z;
+            d.bb_max[0] = mx.x; d.bb_max[1] = mx.y; d.bb_max[2] = mx.z;
+            const Material& m = p.material;
+            std::memcpy(d.material.base_color_factor, m.materialInfo.baseColorFactor, 16);
+            std::memcpy(d.material.emissive_factor, m.materialInfo.emissiveFactor, 16);
+            d.material.normal_scale = m.materialInfo.normalScale; d.material.metallic_factor = m.materialInfo.metallicFactor;
+            d.material.roughness_factor = m.materialInfo.roughnessFactor; d.material.ao_factor = m.materialInfo.aoFactor;
+            d.material.alpha_mode = (int32_t)m.alphaInfo.alphaMode; d.material.alpha_cutoff = m.alphaInfo.alphaCutoff;
+            d.material.albedo_texture = (uint32_t)m.albedoTexture; d.material.normal_texture = (uint32_t)m.normalTexture;
+            d.material.metal_roughness_texture = (uint32_t)m.metalRoughnessTexture; d.material.ao_texture = (uint32_t)m.aoTexture;
+            d.material.emissive_texture = (uint32_t)m.emissiveTexture;
+        }
+        const mat4 model = mesh.node ? mesh.node->modelMatrix() : rdr::mat_identity();
+        uint32_t id = 0;
+        check(RDR_ABI(add_mesh)(ctx, descs.data(), (uint32_t)descs.size(), model.m, mesh.node ? mesh.node->isStatic() : 1, &id), "addMesh");
+        meshes.push_back(MeshSlot{id, mesh.node});
+    }
+
+    Camera& camera() { return _camera; }
+    RendererSettings& settings() { return _settings; }
+    uint32_t width() const { return _width; }
+    uint32_t height() const { return _height; }
+
+    // One iteration of renderLoop (VulkanRenderer.cpp:1013-1110): reads every mesh's node->modelMatrix() (:975), the
+    // camera and the two settings the loop re-reads each frame, renders, returns width*height*4 bytes.
+    std::vector<uint8_t> renderFrame(const FrameParams& fp, float* avgLogLuminance = nullptr) {
+        std::vector<uint8_t> out((size_t)_width * _height * 4);
+        renderFrameInto(fp, out.data(), false, avgLogLuminance);
+        return out;
+    }
+    // `dst` is a host pointer, or a device pointer when dstIsDevice (the frame then stays in HBM)
+    void renderFrameInto(const FrameParams& fp, uint8_t* dst, bool dstIsDevice, float* avgLogLuminance = nullptr) {
+        for (const MeshSlot& m : meshes)
+            if (m.node) { const mat4 model = m.node->modelMatrix(); check(RDR_ABI(set_mesh_transform)(ctx, m.id, model.m), "mesh transform"); }
+        const rdr_camera cam = _camera.toAbi();
+        check(RDR_ABI(set_camera)(ctx, &cam), "camera");
+        check(RDR_ABI(set_exposure_bias)(ctx, _settings.exposureBias, _settings.gamma), "settings");
+        const rdr_frame_params p = {fp.exposureMode, fp.deltaTime, fp.temporalLuminance, fp.exposure};
+        check(RDR_ABI(render_frame)(ctx, &p, dst, dstIsDevice ? 1 : 0, avgLogLuminance), "renderFrame");
+    }
+    rdr_frame_stats frameStats() {
+        rdr_frame_stats s;
+        check(RDR_ABI(get_frame_stats)(ctx, &s), "frameStats");
+        return s;
+    }
+    rdr_ctx* handle() { return ctx; }
+
+private:
+    struct MeshSlot { uint32_t id; std::shared_ptr<Node> node; };
+    void check(int rc, const char* what) {
+        if (rc != RDR_OK) throw std::runtime_error(std::string(what) + ": status " + std::to_string(rc) + ": " + RDR_ABI(last_error)(ctx));
+    }
+    rdr_ctx* ctx = nullptr;
+    RendererSettings _settings;
+    Camera _camera;
+    uint32_t _width, _height;
+    std::vector<Node*> rootNodes;
+    std::vector<MeshSlot> meshes;
+    std::atomic<bool> running{false};
+    std::thread renderThread;
+    std::mutex latestMutex;
+    std::vector<uint8_t> latest;
+    uint64_t framesRendered = 0;
+};
+
+using VulkanRenderer = Renderer;  // the name host code written against the reference uses
+
+}  // namespace hiprenderer

@@ -17,7 +17,7 @@
 
 #include "../../include/rdr.h"
 #include "kernels.h"
-#include "rdr_host_math.h"
+#include "../../include/rdr_math.h"
 
 using namespace rdr;
 
