@@ -635,3 +635,9 @@ int orc_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_
 }
 
 }  // extern "C"
+
+// Test hook (not part of the rdr.h ABI): texel (i, j) of a cube face, folded over the cube edge when one step outside.
+extern "C" void orc_test_cube_fold(int face, int i, int j, int r, int out[3]) {
+    const size_t o = orc::cube_texel_offset(face, i, j, r);
+    out[0] = (int)(o / ((size_t)r * r)); out[1] = (int)(o % r); out[2] = (int)((o / r) % r);
+}

@@ -27,21 +27,60 @@ static inline int cube_face(float rx, float ry, float rz, float& s, float& t) {
     return face;
 }
 
+// Texel (i, j) of `face` at resolution r, where i or j may be one step outside [0, r): the texel across the cube
+// edge. Vulkan filters linearly across cube faces (seamless cube maps are the default), which makes a lookup
+// continuous in its direction. Texel centres are odd integers on a grid of half-texel steps, U = 2i + 1 - r in
+// (-r, r) on a face at distance r; a step outside is folded over the edge (distance r - 1 on the old major axis,
+// r on the crossed one), so the along-edge index carries over exactly. At a corner (both outside) the t index is
+// clamped first. Integer arithmetic only.
+ void cube_fold(int face, int i, int j, int r, int& face_out, int& i_out, int& j_out) {
+    if (i >= 0 && i < r && j >= 0 && j < r) { face_out = face; i_out = i; j_out = j; return; }
+    if ((i < 0 || i >= r) && (j < 0 || j >= r)) j = j < 0 ? 0 : r - 1;
+    int U = 2 * i + 1 - r, V = 2 * j + 1 - r, M = r;
+    if (U > r) { M = 2 * r - U; U = r; } else if (U < -r) { M = 2 * r + U; U = -r; }
+    else if (V > r) { M = 2 * r - V; V = r; } else if (V < -r) { M = 2 * r + V; V = -r; }
+    int X, Y, Z;  // point on the cube, components in half-texel units
+    switch (face) {
+        case 0: X = M; Y = -V; Z = -U; break;
+        case 1: X = -M; Y = -V; Z = U; break;
+        case 2: X = U; Y = M; Z = V; break;
+        case 3: X = U; Y = -M; Z = -V; break;
+        case 4: X = U; Y = -V; Z = M; break;
+        default: X = -U; Y = -V; Z = -M; break;
+    }
+    const int ax = X < 0 ? -X : X, ay = Y < 0 ? -Y : Y, az = Z < 0 ? -Z : Z;
+    int sc, tc;
+    if (az >= ax && az >= ay) { face_out = Z < 0 ? 5 : 4; sc = Z < 0 ? -X : X; tc = -Y; }
+    else if (ay >= ax) { face_out = Y < 0 ? 3 : 2; sc = X; tc = Y < 0 ? -Z : Z; }
+    else { face_out = X < 0 ? 1 : 0; sc = X < 0 ? Z : -Z; tc = -Y; }
+    i_out = (sc + r - 1) / 2;
+    j_out = (tc + r - 1) / 2;
+    i_out = i_out < 0 ? 0 : (i_out > r - 1 ? r - 1 : i_out);
+    j_out = j_out < 0 ? 0 : (j_out > r - 1 ? r - 1 : j_out);
+}
+
+// face-local texel index of (i, j) folded over the edges, as an offset into one level
+size_t cube_texel_offset(int face, int i, int j, int r) {
+    int f2, i2, j2;
+    cube_fold(face, i, j, r, f2, i2, j2);
+    return ((size_t)f2 * r + j2) * r + i2;
+}
+
 void cube_sample(const Cube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
     float s, t;
     const int face = cube_face(dx, dy, dz, s, t);
     const int r = (int)std::max(1u, cube.res >> level);
-    const uint32_t* px = cube.level[level].data() + (size_t)face * r * r;
+    const uint32_t* px = cube.level[level].data();
     const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
     const float fu = std::floor(tu), fv = std::floor(tv);
     const float a = tu - fu, b = tv - fv;
-    const int i0 = std::min(std::max((int)fu, 0), r - 1), i1 = std::min(std::max((int)fu + 1, 0), r - 1);
-    const int j0 = std::min(std::max((int)fv, 0), r - 1), j1 = std::min(std::max((int)fv + 1, 0), r - 1);
+    // s, t lie in [0, 1], so the four texels are at most one step outside the face
+    const int i0 = std::min(std::max((int)fu, -1), r - 1), j0 = std::min(std::max((int)fv, -1), r - 1);
     float c00[3], c10[3], c01[3], c11[3];
-    unpack_r11g11b10(px[(size_t)j0 * r + i0], c00[0], c00[1], c00[2]);
-    unpack_r11g11b10(px[(size_t)j0 * r + i1], c10[0], c10[1], c10[2]);
-    unpack_r11g11b10(px[(size_t)j1 * r + i0], c01[0], c01[1], c01[2]);
-    unpack_r11g11b10(px[(size_t)j1 * r + i1], c11[0], c11[1], c11[2]);
+    unpack_r11g11b10(px[cube_texel_offset(face, i0, j0, r)], c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(px[cube_texel_offset(face, i0 + 1, j0, r)], c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(px[cube_texel_offset(face, i0, j0 + 1, r)], c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(px[cube_texel_offset(face, i0 + 1, j0 + 1, r)], c11[0], c11[1], c11[2]);
     for (int k = 0; k < 3; k++) {
         const float top = (1.0f - a) * c00[k] + a * c10[k], bot = (1.0f - a) * c01[k] + a * c11[k];
         out[k] = (1.0f - b) * top + b * bot;

@@ -13,6 +13,8 @@
 // written here, which the HIP path repeats operation for operation.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "orc_types.h"
 
@@ -57,8 +59,8 @@ static float shadow_pcf(const float* map, int res, float s, float t, float ref) 
     const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
     return (1.0f - b) * top + b * bot;
 }
-// samplerCubeArrayShadow: face selection per the Vulkan tables, bilinear PCF
-// inside the face with clamp-to-edge.
+// samplerCubeArrayShadow: face selection per the Vulkan tables, bilinear PCF;
+// texels one step outside the face come from the neighbouring face (seamless).
 static float shadow_cube(const Ctx& c, uint32_t slot, float rx, float ry, float rz, float ref) {
     const int res = (int)c.settings.point_shadow_map_resolution;
     const float ax = std::fabs(rx), ay = std::fabs(ry), az = std::fabs(rz);
@@ -67,14 +69,13 @@ static float shadow_cube(const Ctx& c, uint32_t slot, float rx, float ry, float 
     else if (ay >= ax) { face = ry < 0.0f ? 3 : 2; sc = rx; tc = ry < 0.0f ? -rz : rz; ma = ay; }
     else { face = rx < 0.0f ? 1 : 0; sc = rx < 0.0f ? rz : -rz; tc = -ry; ma = ax; }
     const float s = 0.5f * (sc / ma) + 0.5f, t = 0.5f * (tc / ma) + 0.5f;
-    const float* map = c.point_shadow.data() + ((size_t)slot * 6 + face) * res * res;
+    const float* map = c.point_shadow.data() + (size_t)slot * 6 * res * res;  // the six faces of this cube
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = std::floor(tu), fv = std::floor(tv);
     const float a = tu - fu, b = tv - fv;
-    const int i0 = std::min(std::max((int)fu, 0), res - 1), i1 = std::min(std::max((int)fu + 1, 0), res - 1);
-    const int j0 = std::min(std::max((int)fv, 0), res - 1), j1 = std::min(std::max((int)fv + 1, 0), res - 1);
-    const float r00 = ref <= map[(size_t)j0 * res + i0] ? 1.0f : 0.0f, r10 = ref <= map[(size_t)j0 * res + i1] ? 1.0f : 0.0f;
-    const float r01 = ref <= map[(size_t)j1 * res + i0] ? 1.0f : 0.0f, r11 = ref <= map[(size_t)j1 * res + i1] ? 1.0f : 0.0f;
+    const int i0 = std::min(std::max((int)fu, -1), res - 1), j0 = std::min(std::max((int)fv, -1), res - 1);
+    const float r00 = ref <= map[cube_texel_offset(face, i0, j0, res)] ? 1.0f : 0.0f, r10 = ref <= map[cube_texel_offset(face, i0 + 1, j0, res)] ? 1.0f : 0.0f;
+    const float r01 = ref <= map[cube_texel_offset(face, i0, j0 + 1, res)] ? 1.0f : 0.0f, r11 = ref <= map[cube_texel_offset(face, i0 + 1, j0 + 1, res)] ? 1.0f : 0.0f;
     const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
     return (1.0f - b) * top + b * bot;
 }
@@ -233,7 +234,13 @@ static void shade_fragment(const ShadeCtx& sc, const Draw& d, uint32_t tri, int 
     //   (far - far*near/d) / (far - near) = c0 - c1/d with c0 = far/(far-near), c1 = far*near/(far-near).
     const float far = 100.0f, near = 0.1f;
     const float c0 = far / (far - near), c1 = (far * near) / (far - near);
+    static const char* dbg_env = std::getenv("ORC_DEBUG_PIXEL");
+    int dbg_x = -1, dbg_y = -1;
+    if (dbg_env) std::sscanf(dbg_env, "%d,%d", &dbg_x, &dbg_y);
+    const bool dbg = px == dbg_x && py == dbg_y;
+    if (dbg) std::fprintf(stderr, "[orc] px %d %d tri %u P %.9g %.9g %.9g N %.9g %.9g %.9g rough %.9g metal %.9g\n", px, py, tri, P.x, P.y, P.z, N.x, N.y, N.z, roughness, metallic);
     for (const PointLight& pl : c.lights) {
+        if (dbg) std::fprintf(stderr, "[orc]   Lo %.9g %.9g %.9g (before light at %.3g %.3g %.3g)\n", Lo.x, Lo.y, Lo.z, pl.point.x, pl.point.y, pl.point.z);
         const V3 Lv = pl.point - P;
         const float d2 = dot(Lv, Lv);
         if (std::max(pl.intensity.x, std::max(pl.intensity.y, pl.intensity.z)) <= 1e-3f * d2) continue;
@@ -243,6 +250,7 @@ static void shade_fragment(const ShadeCtx& sc, const Draw& d, uint32_t tri, int 
             float lightDepth = std::max(std::fabs(Lv.x), std::max(std::fabs(Lv.y), std::fabs(Lv.z))) - 0.05f;
             lightDepth = c0 - c1 / lightDepth;
             const float shadowTest = shadow_cube(c, pl.shadow_map_index, -Lv.x, -Lv.y, -Lv.z, lightDepth);
+            if (dbg) std::fprintf(stderr, "[orc]     slot %u ref %.9g shadowTest %.9g\n", pl.shadow_map_index, lightDepth, shadowTest);
             if (shadowTest < 1e-3f) continue;
             const V3 r = BRDF(radiance, normalize(Lv), N, V, alb, roughness, metallic, F0);
             Lo = Lo + r * shadowTest;
@@ -266,6 +274,7 @@ static void shade_fragment(const ShadeCtx& sc, const Draw& d, uint32_t tri, int 
         }
         const int layer = std::min(split, ncasc - 1);  // array layer is clamped by the sampler
         const float shadowTest = shadow_pcf(c.dir_shadow.data() + (size_t)layer * res * res, res, ls[0], ls[1], ls[2]);
+        if (dbg) std::fprintf(stderr, "[orc]   Lo %.9g %.9g %.9g before dir; layer %d ls %.9g %.9g %.9g shadowTest %.9g\n", Lo.x, Lo.y, Lo.z, layer, ls[0], ls[1], ls[2], shadowTest);
         if (shadowTest > 1e-3f) {
             const Quat q{c.dir_light.orientation_wxyz[0], c.dir_light.orientation_wxyz[1], c.dir_light.orientation_wxyz[2], c.dir_light.orientation_wxyz[3]};
             const V3 L = normalize(rotate(q, V3{0.0f, 0.0f, 1.0f}));
@@ -314,6 +323,7 @@ static void shade_fragment(const ShadeCtx& sc, const Draw& d, uint32_t tri, int 
         Lo = Lo + V3{add[0], add[1], add[2]};
     }
 
+    if (dbg) std::fprintf(stderr, "[orc]   Lo %.9g %.9g %.9g final, emissive %.9g %.9g %.9g\n", Lo.x, Lo.y, Lo.z, emissive[0], emissive[1], emissive[2]);
     out[0] = std::min(Lo.x + emissive[0], 10.0f);
     out[1] = std::min(Lo.y + emissive[1], 10.0f);
     out[2] = std::min(Lo.z + emissive[2], 10.0f);

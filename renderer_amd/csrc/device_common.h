@@ -109,23 +109,73 @@ RDR_DEV int cube_face(float rx, float ry, float rz, float& s, float& t) {
     t = 0.5f * (tc / ma) + 0.5f;
     return face;
 }
+// Texel (i, j) of `face` at resolution r, where i or j may be one step outside [0, r): the texel across the cube
+// edge. Vulkan filters linearly across cube faces (seamless cube maps are the default), which makes a lookup
+// continuous in its direction. Texel centres are odd integers on a grid of half-texel steps, U = 2i + 1 - r in
+// (-r, r) on a face at distance r; a step outside is folded over the edge (distance r - 1 on the old major axis,
+// r on the crossed one), so the along-edge index carries over exactly. At a corner (both outside) the t index is
+// clamped first. Integer arithmetic only.
+RDR_DEV void cube_fold(int face, int i, int j, int r, int& face_out, int& i_out, int& j_out) {
+    if (i >= 0 && i < r && j >= 0 && j < r) { face_out = face; i_out = i; j_out = j; return; }
+    if ((i < 0 || i >= r) && (j < 0 || j >= r)) j = j < 0 ? 0 : r - 1;
+    int U = 2 * i + 1 - r, V = 2 * j + 1 - r, M = r;
+    if (U > r) { M = 2 * r - U; U = r; } else if (U < -r) { M = 2 * r + U; U = -r; }
+    else if (V > r) { M = 2 * r - V; V = r; } else if (V < -r) { M = 2 * r + V; V = -r; }
+    int X, Y, Z;  // point on the cube, components in half-texel units
+    switch (face) {
+        case 0: X = M; Y = -V; Z = -U; break;
+        case 1: X = -M; Y = -V; Z = U; break;
+        case 2: X = U; Y = M; Z = V; break;
+        case 3: X = U; Y = -M; Z = -V; break;
+        case 4: X = U; Y = -V; Z = M; break;
+        default: X = -U; Y = -V; Z = -M; break;
+    }
+    const int ax = X < 0 ? -X : X, ay = Y < 0 ? -Y : Y, az = Z < 0 ? -Z : Z;
+    int sc, tc;
+    if (az >= ax && az >= ay) { face_out = Z < 0 ? 5 : 4; sc = Z < 0 ? -X : X; tc = -Y; }
+    else if (ay >= ax) { face_out = Y < 0 ? 3 : 2; sc = X; tc = Y < 0 ? -Z : Z; }
+    else { face_out = X < 0 ? 1 : 0; sc = X < 0 ? Z : -Z; tc = -Y; }
+    i_out = (sc + r - 1) / 2;
+    j_out = (tc + r - 1) / 2;
+    i_out = i_out < 0 ? 0 : (i_out > r - 1 ? r - 1 : i_out);
+    j_out = j_out < 0 ? 0 : (j_out > r - 1 ? r - 1 : j_out);
+}
+RDR_DEV uint32_t cube_texel_offset(int face, int i, int j, int r) {
+    int f2, i2, j2;
+    cube_fold(face, i, j, r, f2, i2, j2);
+    return (uint32_t)((f2 * r + j2) * r + i2);
+}
+// Offsets of the 2x2 footprint at (i0, j0), i0/j0 in [-1, r-1]. The common case (all four inside the face) costs
+// four adds; only footprints that touch the border of a face go through the fold.
+RDR_DEV void cube_footprint(int face, int i0, int j0, int r, uint32_t o[4]) {
+    if (i0 >= 0 && j0 >= 0 && i0 + 1 < r && j0 + 1 < r) {
+        const uint32_t base = (uint32_t)((face * r + j0) * r + i0);
+        o[0] = base; o[1] = base + 1u; o[2] = base + (uint32_t)r; o[3] = base + (uint32_t)r + 1u;
+    } else {
+        o[0] = cube_texel_offset(face, i0, j0, r); o[1] = cube_texel_offset(face, i0 + 1, j0, r);
+        o[2] = cube_texel_offset(face, i0, j0 + 1, r); o[3] = cube_texel_offset(face, i0 + 1, j0 + 1, r);
+    }
+}
+
+// Bit-exact variant (IEEE divides, weights as (1-a)*x + a*y): used by the bakes, whose outputs are compared
+// bit for bit with the CPU checker.
 RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
     float s, t;
     const int face = cube_face(dx, dy, dz, s, t);
     const uint32_t rr = cube.res >> level;
     const int r = (int)(rr ? rr : 1u);
-    const uint32_t* px = cube.texels + cube.level_offset[level] + (size_t)face * r * r;
+    const RDR_GLOBAL uint32_t* px = as_global(cube.texels) + cube.level_offset[level];
     const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
-    const int i0 = min(max((int)fu, 0), r - 1), i1 = min(max((int)fu + 1, 0), r - 1);
-    const int j0 = min(max((int)fv, 0), r - 1), j1 = min(max((int)fv + 1, 0), r - 1);
-    const uint32_t q00 = px[j0 * r + i0], q10 = px[j0 * r + i1], q01 = px[j1 * r + i0], q11 = px[j1 * r + i1];
+    const int i0 = min(max((int)fu, -1), r - 1), j0 = min(max((int)fv, -1), r - 1);
+    uint32_t o[4];
+    cube_footprint(face, i0, j0, r, o);
     float c00[3], c10[3], c01[3], c11[3];
-    unpack_r11g11b10(q00, c00[0], c00[1], c00[2]);
-    unpack_r11g11b10(q10, c10[0], c10[1], c10[2]);
-    unpack_r11g11b10(q01, c01[0], c01[1], c01[2]);
-    unpack_r11g11b10(q11, c11[0], c11[1], c11[2]);
+    unpack_r11g11b10(px[o[0]], c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(px[o[1]], c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(px[o[2]], c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(px[o[3]], c11[0], c11[1], c11[2]);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float top = (1.0f - a) * c00[k] + a * c10[k], bot = (1.0f - a) * c01[k] + a * c11[k];
@@ -142,8 +192,8 @@ RDR_DEV int cube_face_fast(float rx, float ry, float rz, float& s, float& t) {
     else if (ay >= ax) { face = ry < 0.0f ? 3 : 2; sc = rx; tc = ry < 0.0f ? -rz : rz; ma = ay; }
     else { face = rx < 0.0f ? 1 : 0; sc = rx < 0.0f ? rz : -rz; tc = -ry; ma = ax; }
     const float hinv = 0.5f * __builtin_amdgcn_rcpf(ma);
-    s = fmaf(sc, hinv, 0.5f);
-    t = fmaf(tc, hinv, 0.5f);
+    s = fminf(fmaxf(fmaf(sc, hinv, 0.5f), 0.0f), 1.0f);
+    t = fminf(fmaxf(fmaf(tc, hinv, 0.5f), 0.0f), 1.0f);
     return face;
 }
 RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
@@ -151,18 +201,18 @@ RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float
     const int face = cube_face_fast(dx, dy, dz, s, t);
     const uint32_t rr = cube.res >> level;
     const int r = (int)(rr ? rr : 1u);
-    const RDR_GLOBAL uint32_t* px = as_global(cube.texels) + cube.level_offset[level] + (size_t)face * r * r;
+    const RDR_GLOBAL uint32_t* px = as_global(cube.texels) + cube.level_offset[level];
     const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
-    const int i0 = min(max((int)fu, 0), r - 1), i1 = min(max((int)fu + 1, 0), r - 1);
-    const int j0 = min(max((int)fv, 0), r - 1), j1 = min(max((int)fv + 1, 0), r - 1);
-    const uint32_t q00 = px[j0 * r + i0], q10 = px[j0 * r + i1], q01 = px[j1 * r + i0], q11 = px[j1 * r + i1];
+    const int i0 = min(max((int)fu, -1), r - 1), j0 = min(max((int)fv, -1), r - 1);
+    uint32_t o[4];
+    cube_footprint(face, i0, j0, r, o);
     float c00[3], c10[3], c01[3], c11[3];
-    unpack_r11g11b10(q00, c00[0], c00[1], c00[2]);
-    unpack_r11g11b10(q10, c10[0], c10[1], c10[2]);
-    unpack_r11g11b10(q01, c01[0], c01[1], c01[2]);
-    unpack_r11g11b10(q11, c11[0], c11[1], c11[2]);
+    unpack_r11g11b10(px[o[0]], c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(px[o[1]], c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(px[o[2]], c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(px[o[3]], c11[0], c11[1], c11[2]);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float top = fmaf(a, c10[k] - c00[k], c00[k]), bot = fmaf(a, c11[k] - c01[k], c01[k]);

@@ -57,14 +57,15 @@ RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, f
     const int res = (int)fr.point_res;
     float s, t;
     const int face = cube_face_fast(rx, ry, rz, s, t);  // the PCF result is continuous in (s,t)
-    const RDR_GLOBAL float* map = as_global(fr.point_shadow) + ((size_t)slot * 6 + face) * res * res;
+    const RDR_GLOBAL float* map = as_global(fr.point_shadow) + (size_t)slot * 6 * res * res;  // the six faces of this cube
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
-    const int i0 = min(max((int)fu, 0), res - 1), i1 = min(max((int)fu + 1, 0), res - 1);
-    const int j0 = min(max((int)fv, 0), res - 1), j1 = min(max((int)fv + 1, 0), res - 1);
-    const float r00 = ref <= map[j0 * res + i0] ? 1.0f : 0.0f, r10 = ref <= map[j0 * res + i1] ? 1.0f : 0.0f;
-    const float r01 = ref <= map[j1 * res + i0] ? 1.0f : 0.0f, r11 = ref <= map[j1 * res + i1] ? 1.0f : 0.0f;
+    const int i0 = min(max((int)fu, -1), res - 1), j0 = min(max((int)fv, -1), res - 1);
+    uint32_t o[4];
+    cube_footprint(face, i0, j0, res, o);  // texels beyond the face come from its neighbour (seamless cube filtering)
+    const float r00 = ref <= map[o[0]] ? 1.0f : 0.0f, r10 = ref <= map[o[1]] ? 1.0f : 0.0f;
+    const float r01 = ref <= map[o[2]] ? 1.0f : 0.0f, r11 = ref <= map[o[3]] ? 1.0f : 0.0f;
     const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
     return (1.0f - b) * top + b * bot;
 }

@@ -383,3 +383,35 @@ def test_packed_float_storage_truncates(orc_capi):
         lo_r, lo_b = trunc(v, 6), trunc(v, 5)
         assert m0[0, i, 0] >= lo_r - 1e-12 and m0[0, i, 2] >= lo_b - 1e-12
     assert m0[0, 9, 0] <= m0[0, 0, 0] + 1e-6  # negative input stored as 0 (only neighbours' bloom remains)
+
+
+def test_cube_edge_fold_is_the_geometric_neighbour(orc_capi):
+    """Seamless cube filtering: a texel one step outside a face is the texel across the shared edge. Checked
+    against geometry: with face coordinates as in the Vulkan cube tables (sc, tc per face), the centre of the texel
+    returned for (i = -1 or r, j) lies on another face, at distance sqrt(2)/r from the centre of the edge texel it
+    continues (both are half a texel from the shared edge, at the same position along it)."""
+    import ctypes as C
+    fold = orc_capi.lib.orc_test_cube_fold
+    fold.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    fold.restype = None
+
+    def centre(face, i, j, r):
+        sc, tc = (2 * i + 1) / r - 1, (2 * j + 1) / r - 1
+        return np.array({0: (1, -tc, -sc), 1: (-1, -tc, sc), 2: (sc, 1, tc), 3: (sc, -1, -tc), 4: (sc, -tc, 1), 5: (-sc, -tc, -1)}[face])
+
+    for r in (1, 2, 5, 16):
+        out = (C.c_int * 3)()
+        for face in range(6):
+            for k in range(r):
+                fold(face, k, k, r, out)
+                assert tuple(out) == (face, k, k)
+                for (i, j, ci, cj) in ((-1, k, 0, k), (r, k, r - 1, k), (k, -1, k, 0), (k, r, k, r - 1)):
+                    fold(face, i, j, r, out)
+                    f2, i2, j2 = out
+                    assert f2 != face and 0 <= i2 < r and 0 <= j2 < r
+                    d = np.linalg.norm(centre(f2, i2, j2, r) - centre(face, ci, cj, r))
+                    assert abs(d - np.sqrt(2) / r) < 1e-12, (r, face, i, j, tuple(out))
+            # corners resolve to a texel of a neighbouring face that touches the corner
+            for (i, j) in ((-1, -1), (r, -1), (-1, r), (r, r)):
+                fold(face, i, j, r, out)
+                assert out[0] != face and out[1] in (0, r - 1) and out[2] in (0, r - 1)
