@@ -60,29 +60,27 @@ RDR_DEV void unpack_half4(uint2 p, float& r, float& g, float& b, float& a) {
 // ---- B10G11R11_UFLOAT: 5 exponent bits, MB mantissa bits, no sign. Negative
 // -> 0, NaN -> NaN, +inf -> inf, above the largest finite -> largest finite,
 // mantissa truncated, denormals kept.
-template <int MB> RDR_DEV uint32_t float_to_ufloat(float f) {
-    const uint32_t x = __float_as_uint(f);
-    const uint32_t max_finite = (30u << MB) | ((1u << MB) - 1u);
-    if ((x & 0x7FFFFFFFu) > 0x7F800000u) return (31u << MB) | 1u;
-    if (x & 0x80000000u) return 0u;
-    if (x == 0x7F800000u) return 31u << MB;
-    const int e = (int)(x >> 23) - 127;
-    const uint32_t m = x & 0x7FFFFFu;
-    if (e > 15) return max_finite;
-    if (e >= -14) return ((uint32_t)(e + 15) << MB) | (m >> (23 - MB));
-    const int shift = (23 - MB) + (-14 - e);
-    if (shift > 24) return 0u;
-    return (m | 0x800000u) >> shift;
+// The format has binary16's exponent field, so it is binary16 with the sign
+// and the low 10 - MB mantissa bits dropped: encoding is one
+// round-toward-zero conversion to half (which also saturates finite overflow
+// to 65504, whose top bits are the largest finite packed value) and a shift;
+// decoding is a shift and a half -> float conversion.
+typedef __fp16 rdr_half2_t __attribute__((ext_vector_type(2)));
+RDR_DEV uint32_t half2_bits_rtz(float a, float b) {
+    const rdr_half2_t h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
 }
-template <int MB> RDR_DEV float ufloat_to_float(uint32_t v) {
-    // normal numbers: re-bias the exponent by 127 - 15; Inf/NaN (e == 31) need 255 instead of 143
-    uint32_t bits = (v << (23 - MB)) + (112u << 23);
-    if (v >= (31u << MB)) bits += 112u << 23;
-    const float den = (float)v * __uint_as_float((uint32_t)(127 - 14 - MB) << 23);  // e == 0: v is the mantissa
-    return v < (1u << MB) ? den : __uint_as_float(bits);
+template <int MB> RDR_DEV uint32_t ufloat_from_half_bits(uint32_t h) {  // h: one binary16 in the low 16 bits
+    const uint32_t mag = h & 0x7FFFu;
+    if (mag > 0x7C00u) return (31u << MB) | 1u;  // NaN of either sign
+    return (h & 0x8000u) ? 0u : mag >> (10 - MB);
 }
+template <int MB> RDR_DEV float ufloat_to_float(uint32_t v) { return f16_bits_to_f32(v << (10 - MB)); }
 RDR_DEV uint32_t pack_r11g11b10(float r, float g, float b) {
-    return float_to_ufloat<6>(r) | (float_to_ufloat<6>(g) << 11) | (float_to_ufloat<5>(b) << 22);
+    const uint32_t rg = half2_bits_rtz(r, g), b0 = half2_bits_rtz(b, 0.0f);
+    return ufloat_from_half_bits<6>(rg & 0xFFFFu) | (ufloat_from_half_bits<6>(rg >> 16) << 11) | (ufloat_from_half_bits<5>(b0 & 0xFFFFu) << 22);
 }
 RDR_DEV void unpack_r11g11b10(uint32_t p, float& r, float& g, float& b) {
     r = ufloat_to_float<6>(p & 0x7FFu);

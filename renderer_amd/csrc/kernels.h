@@ -12,11 +12,11 @@ struct IrradianceTables {  // sin/cos of the 24 azimuth and 6 polar angles of en
 };
 
 // kernels_post.hip
-void launch_hdr_to_bloom0(hipStream_t s, const void* hdr, uint32_t* bloom0, uint32_t n);
-void launch_bloom_down(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int dst_pitch);
+void launch_bloom_down(hipStream_t s, const void* src, bool src_is_hdr, int sw, int sh, uint32_t* dst, int dw, int dh, int dst_pitch);
 void launch_bloom_up(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int dst_pitch);
-void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* bloom0, uint32_t* out, float* loglum, uint32_t n, float scale,
-                    float inv_gamma, float white, float log2_6);
+// last up-sample (mip 1 -> mip 0) fused with the tonemap; sw/sh = 0 when the image has no mip 1
+void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* mip1, int sw, int sh, uint32_t* bloom0, uint32_t* out, float* loglum,
+                    int W, int H, float scale, float inv_gamma, float white, float log2_6);
 void launch_average_luminance(hipStream_t s, const float* loglum, int W, int H, float* l16, float* l1);
 
 // kernels_sort.hip

@@ -577,21 +577,20 @@ int ensure_post_targets(rdr_ctx* c) {
 
 // bloom chain + tonemap + average luminance (VulkanRendererBloom.cpp:62-100, VulkanRenderer.cpp:1084-1109, 1156-1191)
 void enqueue_post(rdr_ctx* c, float exposure) {
-    const uint32_t n = c->W * c->H;
     uint32_t* bloom = c->d_bloom.as<uint32_t>();
     (void)hipEventRecord(c->ev[2], c->stream);
-    launch_hdr_to_bloom0(c->stream, c->d_hdr.p, bloom, n);
+    // mip 0 is the colour image itself until the tonemap kernel stores its final value
     for (uint32_t i = 0; i < 5; i++)
-        launch_bloom_down(c->stream, bloom + c->bloom_offset[i], (int)c->bloom_w[i], (int)c->bloom_h[i], bloom + c->bloom_offset[i + 1],
-                          (int)(c->W >> (i + 1)), (int)(c->H >> (i + 1)), (int)c->bloom_w[i + 1]);
-    for (uint32_t i = 0; i < 5; i++) {
+        launch_bloom_down(c->stream, i == 0 ? c->d_hdr.p : (const void*)(bloom + c->bloom_offset[i]), i == 0, (int)c->bloom_w[i], (int)c->bloom_h[i],
+                          bloom + c->bloom_offset[i + 1], (int)(c->W >> (i + 1)), (int)(c->H >> (i + 1)), (int)c->bloom_w[i + 1]);
+    for (uint32_t i = 0; i < 4; i++) {
         const uint32_t dl = 4 - i, sl = 5 - i;
         launch_bloom_up(c->stream, bloom + c->bloom_offset[sl], (int)c->bloom_w[sl], (int)c->bloom_h[sl], bloom + c->bloom_offset[dl],
                         (int)(c->W >> dl), (int)(c->H >> dl), (int)c->bloom_w[dl]);
     }
     (void)hipEventRecord(c->ev[3], c->stream);
-    launch_tonemap(c->stream, c->d_hdr.p, bloom, c->d_out.as<uint32_t>(), c->d_loglum.as<float>(), n, powf(2.0f, exposure),
-                   1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
+    launch_tonemap(c->stream, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, c->d_out.as<uint32_t>(),
+                   c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
     launch_average_luminance(c->stream, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), c->d_lum.as<float>() + 256);
     (void)hipEventRecord(c->ev[4], c->stream);
     c->have_post = true;
