@@ -34,6 +34,24 @@ def shade_flops_per_px(n_point_lights):
     return 90.0 * (1 + n_point_lights) + 250.0
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` (FETCH_SIZE + WRITE_SIZE) from the PMC passes committed under profiles/
+    (tools/profile_gpu.sh + tools/pmc_summary.py, the same bench command); None when no summary is there."""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt"))):
+        block = re.search(r"^" + re.escape(kernel) + r":.*?(?=^\S)", open(f).read() + "\nend", re.S | re.M)
+        if not block:
+            continue
+        m_f = re.search(r"FETCH_SIZE\s+n=\d+\s+mean=([0-9.e+]+)", block.group(0))
+        m_w = re.search(r"WRITE_SIZE\s+n=\d+\s+mean=([0-9.e+]+)", block.group(0))
+        if m_f and m_w:
+            best = {"bytes": (float(m_f.group(1)) + float(m_w.group(1))) * 1024.0, "source": os.path.basename(f),
+                    "note": "FETCH_SIZE + WRITE_SIZE, KiB -> bytes, uncorrected (4-byte gathers: uncalibrated on gfx950)"}
+    return best
+
+
 def camera_for_frame(r, k):
     """Camera path down the hall; frame k of the job."""
     t = (k % 240) / 240.0
@@ -157,7 +175,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}, RCCL gather of RGBA8 frames to rank 0" if world > 1 else "single GPU",
                        "lavapipe_oracle": "not available; CPU restatement used"},
             "roofline": {"kernel": "k_shade_opaque", "bound": "valu_fp32", "achieved": shade_tf, "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": shade_tf / VALU_FP32_PEAK_TF, "traffic": None, "ms": shade_ms,
+                         "frac": shade_tf / VALU_FP32_PEAK_TF, "traffic": measured_traffic("k_shade_opaque<4>"), "ms": shade_ms,
                          "algorithmic": f"{shade_flops_per_px(n_lights):.0f} flop/px x {n_px} px"},
             "roofline_passes": [
                 {"pass": "bloom chain + tonemap + luminance", "bound": "hbm", "achieved": post_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
