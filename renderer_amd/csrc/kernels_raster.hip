@@ -11,11 +11,11 @@
 //             key = global tile id                        -> pairs
 //   (stable radix sort of the pairs by tile: kernels_sort.hip)
 //   k_ranges  list boundaries per tile
-//   k_raster  one 256-thread block per 16x16 tile, one wave per 8x8 quadrant:
-//             records staged through LDS 64 at a time, each wave ballots the
-//             records whose box touches its quadrant and walks the set bits in
-//             order; edge functions are exact 64-bit integers, depth is a
-//             double-precision plane rounded to float, test LESS.
+//   k_raster  one 256-thread block per 16x16 tile: records staged through LDS
+//             64 at a time, the (triangle, pixel) items of their pixel boxes
+//             spread over the threads; edge functions are exact 64-bit
+//             integers, depth is a double-precision plane rounded to float, the
+//             LESS test is an LDS atomic min on (depth, triangle id).
 //
 // Bit-exactness with the CPU checker rests on three things: the fma chains
 // are written out, the edge functions are integer, and double arithmetic is
@@ -246,12 +246,27 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 
 #define RASTER_CHUNK 64
 
+// One 256-thread block per 16x16 tile. Work is spread over (triangle, pixel)
+// items, not over triangles: for every chunk of 64 records the block sums the
+// areas of their pixel boxes inside the tile (prefix sum), and thread k takes
+// items k, k+256, ... - so sixteen 2x2-pixel triangles keep one wave busy
+// where a loop over triangles would leave 60 of its 64 lanes idle on each.
+//
+// Items of different triangles hit the same sample in any order, so the depth
+// test is an LDS 64-bit atomic min on (depth bits << 32 | triangle id): depths
+// are in [0,1], where float order is unsigned-integer order, and triangle ids
+// grow along the tile's list, so the minimum is exactly what a sequential LESS
+// test in list order leaves (the earlier triangle keeps a tie). The key starts
+// as (initial depth << 32 | 0): a fragment at the initial depth never beats
+// it, as LESS demands.
 template <int S>
 __global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views, uint32_t n_views, const DTriRec* __restrict__ recs,
                                                 const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
                                                 const uint32_t* __restrict__ tile_end, uint32_t first_view, uint32_t tile_origin) {
     __shared__ uint32_t lds_rec[RASTER_CHUNK * 32];  // 64 records of 128 bytes
     __shared__ uint32_t lds_ids[RASTER_CHUNK];
+    __shared__ uint32_t lds_prefix[RASTER_CHUNK + 1];
+    __shared__ unsigned long long lds_key[S * 256];  // [sample][pixel of the tile, row-major]
     const uint32_t tile = tile_origin + blockIdx.x;
     // view of this tile: largest v with tile_base <= tile (views are few; block-uniform loop)
     uint32_t v = first_view;
@@ -261,76 +276,113 @@ __global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views,
     if (vw.load == 2u) return;                    // tiles of the blended pass: binned here, rasterised with their shading
     const uint32_t local_tile = tile - vw.tile_base;
     if (local_tile >= vw.tiles_x * vw.tiles_y) return;
-    const int tx = (int)(local_tile % vw.tiles_x), ty = (int)(local_tile / vw.tiles_x);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qx0 = tx * RDR_TILE + (wave & 1) * 8, qy0 = ty * RDR_TILE + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const uint32_t begin = tile_start[tile], end = tile_end[tile];
+    if (vw.load && begin >= end) return;  // nothing to add to what the target holds
+    const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
+    const int tid = (int)threadIdx.x;
+    const int px = ox0 + (tid & 15), py = oy0 + (tid >> 4);
     const bool in_view = px < (int)vw.w && py < (int)vw.h;
     const size_t plane_px = (size_t)vw.w * vw.h;
     const size_t o = (size_t)py * vw.w + px;
 
-    float z[S];
-    uint32_t id[S];
+    uint32_t zi[S];  // bits of the initial depth
 #pragma unroll
     for (int s = 0; s < S; s++) {
-        z[s] = (vw.load && in_view) ? vw.depth[s * plane_px + o] : 1.0f;
-        id[s] = RDR_PAIR_INVALID;
+        zi[s] = __float_as_uint((vw.load && in_view) ? vw.depth[s * plane_px + o] : 1.0f);
+        lds_key[s * 256 + tid] = (unsigned long long)zi[s] << 32;
     }
     const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
-    const uint32_t begin = tile_start[tile], end = tile_end[tile];
-    bool touched = false;
     for (uint32_t base = begin; base < end; base += RASTER_CHUNK) {
         const uint32_t cnt = min((uint32_t)RASTER_CHUNK, end - base);
-        __syncthreads();
-        if (threadIdx.x < cnt) lds_ids[threadIdx.x] = sorted_vals[base + threadIdx.x];
+        __syncthreads();  // the previous chunk's items are done with lds_rec (first pass: the keys are initialised)
+        if ((uint32_t)tid < cnt) lds_ids[tid] = sorted_vals[base + tid];
         __syncthreads();
         // 32 consecutive threads copy one 128-byte record
         for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += 256u)
             lds_rec[dw] = ((const uint32_t*)(recs + lds_ids[dw >> 5]))[dw & 31u];
         __syncthreads();
-        // lane l of each wave looks at record l: does its pixel box touch this wave's 8x8 quadrant?
-        bool hit = false;
-        if ((uint32_t)lane < cnt) {
-            const DTriRec* r = (const DTriRec*)(lds_rec + lane * 32);
-            hit = r->px0 <= qx0 + 7 && r->px1 >= qx0 && r->py0 <= qy0 + 7 && r->py1 >= qy0;
-        }
-        unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int ri = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const DTriRec* r = (const DTriRec*)(lds_rec + ri * 32);
-            const int n = (int)(r->n_view & 255u);
-            const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
-            const uint32_t rid = r->id;
+        // wave 0: area of each record's pixel box inside the tile, inclusive prefix sum over the 64 lanes
+        if (tid < 64) {
+            uint32_t area = 0;
+            if ((uint32_t)tid < cnt) {
+                const DTriRec* r = (const DTriRec*)(lds_rec + tid * 32);
+                const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1);
+                const int by0 = max((int)r->py0, oy0), by1 = min((int)r->py1, oy0 + RDR_TILE - 1);
+                if (bx0 <= bx1 && by0 <= by1) area = (uint32_t)((bx1 - bx0 + 1) * (by1 - by0 + 1));
+            }
+            uint32_t incl = area;
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                const int Px = 256 * px + (S == 1 ? 128 : sxo[s]), Py = 256 * py + (S == 1 ? 128 : syo[s]);
-                bool inside = true;
-                for (int i = 0; i < n; i++) {
-                    const int j = (i + 1 == n) ? 0 : i + 1;
-                    const int Xi = r->X[i], Yi = r->Y[i];
-                    const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
-                    const long long E = (long long)dX * (long long)(Py - Yi) - (long long)dY * (long long)(Px - Xi);
-                    const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
-                    inside = inside && (E >= bias);
-                }
-                if (inside) {
-                    float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
-                    zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
-                    if (zz < z[s]) { z[s] = zz; id[s] = rid; }
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (tid >= d) incl += up;
+            }
+            lds_prefix[tid + 1] = incl;
+            if (tid == 0) lds_prefix[0] = 0u;
+        }
+        __syncthreads();
+        const uint32_t total = lds_prefix[RASTER_CHUNK];
+        for (uint32_t wi = (uint32_t)tid; wi < total; wi += 256u) {
+            uint32_t lo = 0, hi = cnt;  // largest lo with prefix[lo] <= wi
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (hi - lo > 1u) { if (lds_prefix[mid] <= wi) lo = mid; else hi = mid; }
+            }
+            const uint32_t local = wi - lds_prefix[lo];
+            const DTriRec* r = (const DTriRec*)(lds_rec + lo * 32);
+            const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1);
+            const int by0 = max((int)r->py0, oy0);
+            const uint32_t bw = (uint32_t)(bx1 - bx0 + 1);               // 1..16
+            const uint32_t row = (local * (65536u / bw + 1u)) >> 16;     // local / bw, exact for local < 256
+            const int x = bx0 + (int)(local - row * bw), y = by0 + (int)row;
+            const int n = (int)(r->n_view & 255u);
+            const int Px0 = 256 * x, Py0 = 256 * y;
+            uint32_t inside = (1u << S) - 1u;
+            for (int i = 0; i < n; i++) {
+                const int j = (i + 1 == n) ? 0 : i + 1;
+                const int Xi = r->X[i], Yi = r->Y[i];
+                const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                const long long E0 = (long long)dX * (long long)(Py0 - Yi) - (long long)dY * (long long)(Px0 - Xi);
+                const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    const int ax = S == 1 ? 128 : sxo[s], ay = S == 1 ? 128 : syo[s];
+                    const long long E = E0 + ((long long)dX * ay - (long long)dY * ax);
+                    if (E < bias) inside &= ~(1u << s);
                 }
             }
-            touched = true;
+            if (inside) {
+                const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
+                const uint32_t rid = r->id;
+                const int pix = (y - oy0) * RDR_TILE + (x - ox0);
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    if (!(inside & (1u << s))) continue;
+                    const int Px = Px0 + (S == 1 ? 128 : sxo[s]), Py = Py0 + (S == 1 ? 128 : syo[s]);
+                    float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
+                    zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
+                    atomicMin(&lds_key[s * 256 + pix], ((unsigned long long)__float_as_uint(zz) << 32) | rid);
+                }
+            }
         }
     }
+    __syncthreads();
     if (!in_view) return;
-    if (!vw.load || touched) {
+    bool changed = false;
+    unsigned long long key[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = z[s];
+    for (int s = 0; s < S; s++) {
+        key[s] = lds_key[s * 256 + tid];
+        changed = changed || key[s] != ((unsigned long long)zi[s] << 32);
+    }
+    if (!vw.load || changed) {
+#pragma unroll
+        for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
     }
     if (vw.vis) {
 #pragma unroll
-        for (int s = 0; s < S; s++) vw.vis[s * plane_px + o] = id[s];
+        for (int s = 0; s < S; s++)
+            vw.vis[s * plane_px + o] = key[s] != ((unsigned long long)zi[s] << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
     }
 }
 
