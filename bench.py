@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--diag-lights", type=int, default=-1, help="diagnostic only: keep the first N point lights (not the benchmark workload)")
     a = ap.parse_args()
 
     import torch
@@ -96,6 +97,14 @@ def main():
     info = scenes.sponza_like(r, tex_size=a.tex, detail=a.detail)
     build_s = time.time() - t0
     n_lights = 16
+    if a.diag_lights >= 0:
+        lrng = np.random.default_rng(3)
+        lights = []
+        for j in range(4):
+            for i in range(4):
+                lights.append(((-11.25 + i * 7.5, 1.15, -5.25 + j * 3.5), tuple(20.0 + 60.0 * lrng.random(3)), (i + j) % 2 == 0))
+        n_lights = min(a.diag_lights, 16)
+        r.set_lights(lights[:n_lights], scenes.default_directional_light())
 
     # finished frames stay on the device; two staging slots so that the gather of frame k overlaps frame k+1
     from renderer_amd.sharding import FrameSharder

@@ -264,33 +264,29 @@ RDR_DEV void tex_axis(float coord, int n, uint32_t mode, int& i0, int& i1, float
         i1 = wrap_index((int)fc + 1, n, mode);
     }
 }
-template <int MASK>
-RDR_DEV void tex_bilinear(const float* srgb, const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level, float u, float v, float out[4]) {
+// Where a sample lands in an image of given size, levels and wrap modes: the level pair, and per level the four
+// texel offsets (from the start of the image) with the two filter weights. The material's five textures usually
+// share all of that, so it is computed once per fragment and reused for every texture whose geometry matches.
+struct TexLevelTaps { uint32_t o00, o10, o01, o11; float a, b; };
+struct TexTaps {
+    TexLevelTaps lv[2];
+    float f;        // weight of the second level
+    bool two;       // wave-uniform: the second level is fetched
+};
+RDR_DEV void tex_level_taps(const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level, float u, float v, TexLevelTaps& o) {
     const uint32_t ww = (t.wh & 0xFFFFu) >> level, hh = (t.wh >> 16) >> level;
     const int w = (int)(ww ? ww : 1u), h = (int)(hh ? hh : 1u);
-    const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base) + tex_level_offset(t, table, level);
+    const uint32_t base = tex_level_offset(t, table, level);
     const uint32_t flags = t.info >> 5;
     int i0, i1, j0, j1;
-    float a, b;
-    tex_axis(u, w, (flags >> 2) & 3u, i0, i1, a);
-    tex_axis(v, h, (flags >> 4) & 3u, j0, j1, b);
-    const uint32_t q00 = px[j0 * w + i0], q10 = px[j0 * w + i1], q01 = px[j1 * w + i0], q11 = px[j1 * w + i1];
-    const bool is_srgb = (flags & RDR_TEXD_SRGB) != 0u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (!(MASK & (1 << k))) continue;
-        const uint32_t b00 = (q00 >> (8 * k)) & 255u, b10 = (q10 >> (8 * k)) & 255u, b01 = (q01 >> (8 * k)) & 255u, b11 = (q11 >> (8 * k)) & 255u;
-        float t00, t10, t01, t11;
-        if (k < 3 && is_srgb) { t00 = srgb[b00]; t10 = srgb[b10]; t01 = srgb[b01]; t11 = srgb[b11]; }
-        else { t00 = (float)b00 * RDR_INV255; t10 = (float)b10 * RDR_INV255; t01 = (float)b01 * RDR_INV255; t11 = (float)b11 * RDR_INV255; }
-        const float top = fmaf(a, t10 - t00, t00), bot = fmaf(a, t11 - t01, t01);
-        out[k] = fmaf(b, bot - top, top);
-    }
+    tex_axis(u, w, (flags >> 2) & 3u, i0, i1, o.a);
+    tex_axis(v, h, (flags >> 4) & 3u, j0, j1, o.b);
+    o.o00 = base + (uint32_t)(j0 * w + i0); o.o10 = base + (uint32_t)(j0 * w + i1);
+    o.o01 = base + (uint32_t)(j1 * w + i0); o.o11 = base + (uint32_t)(j1 * w + i1);
 }
 // texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2)
-template <int MASK>
-RDR_DEV void tex_sample(const float* srgb, const DTexDesc& t, const DTexture* __restrict__ table, float u, float v, float dudx, float dvdx,
-                        float dudy, float dvdy, float out[4]) {
+RDR_DEV void tex_taps(const DTexDesc& t, const DTexture* __restrict__ table, float u, float v, float dudx, float dvdx, float dudy, float dvdy,
+                      TexTaps& o) {
     const uint32_t levels = t.info & 31u;
     float lambda = 0.0f;
     if (levels > 1u) {
@@ -300,15 +296,59 @@ RDR_DEV void tex_sample(const float* srgb, const DTexDesc& t, const DTexture* __
         if (rho2 > 1.0f) lambda = fminf(0.5f * __log2f(rho2), (float)(levels - 1u));
     }
     // one branch for the whole wave: minified anywhere -> two levels everywhere (a magnified lane blends level 0
-    // with weight 1, which is exact)
-    if (!__any(lambda > 0.0f)) { tex_bilinear<MASK>(srgb, t, table, 0, u, v, out); return; }
+    // with weight 0 for the second level, which is exact)
+    o.two = __any(lambda > 0.0f) != 0;
     const float fl = floorf(lambda);
     const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, levels - 1u);
-    const float f = lambda - fl;
-    float c0[4], c1[4];
-    tex_bilinear<MASK>(srgb, t, table, l0, u, v, c0);
-    tex_bilinear<MASK>(srgb, t, table, l1, u, v, c1);
+    o.f = lambda - fl;
+    tex_level_taps(t, table, l0, u, v, o.lv[0]);
+    if (o.two) tex_level_taps(t, table, l1, u, v, o.lv[1]);
+}
+// texture geometry = size, level count, level-offset rule and wrap modes (not the sRGB bit, not the table index)
+RDR_DEV bool tex_same_geometry(const DTexDesc& x, const DTexDesc& y) {
+    return x.wh == y.wh && ((x.info ^ y.info) & (31u | (0x3Eu << 5))) == 0u;
+}
+template <int MASK>
+RDR_DEV void tex_fetch_level(const float* srgb, const DTexDesc& t, const TexLevelTaps& k, float out[4]) {
+    const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base);
+    const uint32_t q00 = px[k.o00], q10 = px[k.o10], q01 = px[k.o01], q11 = px[k.o11];
+    const bool is_srgb = ((t.info >> 5) & RDR_TEXD_SRGB) != 0u;
+    const float a = k.a, b = k.b;
+    float c00[4], c10[4], c01[4], c11[4];
+    if (is_srgb && (MASK & 7)) {
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (MASK & (1 << k)) out[k] = fmaf(f, c1[k] - c0[k], c0[k]);
+        for (int c = 0; c < 3; c++) {
+            if (!(MASK & (1 << c))) continue;
+            c00[c] = srgb[(q00 >> (8 * c)) & 255u]; c10[c] = srgb[(q10 >> (8 * c)) & 255u];
+            c01[c] = srgb[(q01 >> (8 * c)) & 255u]; c11[c] = srgb[(q11 >> (8 * c)) & 255u];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (!(MASK & (1 << c))) continue;
+            c00[c] = (float)((q00 >> (8 * c)) & 255u) * RDR_INV255; c10[c] = (float)((q10 >> (8 * c)) & 255u) * RDR_INV255;
+            c01[c] = (float)((q01 >> (8 * c)) & 255u) * RDR_INV255; c11[c] = (float)((q11 >> (8 * c)) & 255u) * RDR_INV255;
+        }
+    }
+    if (MASK & 8) {
+        c00[3] = (float)(q00 >> 24) * RDR_INV255; c10[3] = (float)(q10 >> 24) * RDR_INV255;
+        c01[3] = (float)(q01 >> 24) * RDR_INV255; c11[3] = (float)(q11 >> 24) * RDR_INV255;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (!(MASK & (1 << c))) continue;
+        const float top = fmaf(a, c10[c] - c00[c], c00[c]), bot = fmaf(a, c11[c] - c01[c], c01[c]);
+        out[c] = fmaf(b, bot - top, top);
+    }
+}
+template <int MASK>
+RDR_DEV void tex_fetch(const float* srgb, const DTexDesc& t, const TexTaps& k, float out[4]) {
+    tex_fetch_level<MASK>(srgb, t, k.lv[0], out);
+    if (k.two) {
+        float c1[4];
+        tex_fetch_level<MASK>(srgb, t, k.lv[1], c1);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (MASK & (1 << c)) out[c] = fmaf(k.f, c1[c] - out[c], out[c]);
+    }
 }

@@ -209,19 +209,36 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     const float dudy = interp3(lam[2], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdy = interp3(lam[2], T.uv[3], T.uv[4], T.uv[5]) - v0;
     const DShadeTri& mt = T;  // material block and texture descriptors travel with the triangle
 
+#ifndef RDR_DIAG
+#define RDR_DIAG 0  // diagnostic builds only: bit 0 no textures, bit 1 no directional light, bit 2 no IBL, bit 3 nothing after interpolation
+#endif
+    if (RDR_DIAG & 8) { out[0] = P.x + Nv.x + Tv.y + Bv.z; out[1] = u0 + dudx; out[2] = v0 + dvdy + dudy + dvdx; out[3] = 1.0f; return; }
     // ---- pbr.frag main()
-    float t[4];
-    tex_sample<15>(srgb, T.tex[0], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
+    // the five material textures: filter taps from the albedo texture's geometry, recomputed only for a texture
+    // of another size / wrap mode (decided per wave)
+    float t[4] = {0.5f, 0.5f, 0.5f, 1.0f};
+    TexTaps taps0, taps;
+    if (!(RDR_DIAG & 1)) {
+        tex_taps(T.tex[0], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps0);
+        tex_fetch<15>(srgb, T.tex[0], taps0, t);
+    }
     const float albedo[4] = {t[0] * mt.base_color[0], t[1] * mt.base_color[1], t[2] * mt.base_color[2], t[3] * mt.base_color[3]};
     if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
-    tex_sample<6>(srgb, T.tex[2], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
+#define RDR_SAMPLE_SLOT(slot, mask)                                                                              \
+    if (!(RDR_DIAG & 1)) {                                                                                       \
+        taps = taps0;                                                                                            \
+        if (!__all(tex_same_geometry(T.tex[slot], T.tex[0]))) tex_taps(T.tex[slot], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps); \
+        tex_fetch<mask>(srgb, T.tex[slot], taps, t);                                                             \
+    }
+    RDR_SAMPLE_SLOT(2, 6)
     const float metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
     const float roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
-    tex_sample<1>(srgb, T.tex[3], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
+    RDR_SAMPLE_SLOT(3, 1)
     const float ao = t[0] * mt.ao;
-    tex_sample<7>(srgb, T.tex[4], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
+    RDR_SAMPLE_SLOT(4, 7)
     const float emissive[3] = {t[0] * mt.emissive[0], t[1] * mt.emissive[1], t[2] * mt.emissive[2]};
-    tex_sample<7>(srgb, T.tex[1], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, t);
+    RDR_SAMPLE_SLOT(1, 7)
+#undef RDR_SAMPLE_SLOT
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
     const float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f, nz = t[2] * 2.0f - 1.0f;
     const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
@@ -273,7 +290,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     }
 
     // ---- directional light with cascaded shadow maps (pbr.frag:163-183, basic.vert:45-48)
-    if (fr.lights_set) {
+    if (fr.lights_set && !(RDR_DIAG & 2)) {
         const int ncasc = (int)fr.n_cascades, res = (int)fr.dir_res;
         int split = 0;
         float ls0 = 0.0f, ls1 = 0.0f, ls2 = 0.0f;
@@ -292,7 +309,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     }
 
     // ---- image-based lighting (pbr.frag:186-200)
-    if (fr.prefiltered.res && fr.irradiance.res && fr.lut_w) {
+    if (fr.prefiltered.res && fr.irradiance.res && fr.lut_w && !(RDR_DIAG & 4)) {
         const float NdotV = fmaxf(dot3(N, V), 1e-3f);
         const float lod = fminf(roughness * (float)fr.prefiltered.levels, (float)(fr.prefiltered.levels - 1u));
         const float fl = floorf(lod), ff = lod - fl;
