@@ -18,6 +18,13 @@
 // become flat_load (which also ties up the LDS counter). Everything such a pointer can point at here is HBM.
 #define RDR_GLOBAL __attribute__((address_space(1)))
 template <class T> RDR_DEV const RDR_GLOBAL T* as_global(const T* p) { return (const RDR_GLOBAL T*)p; }
+// Two consecutive dwords at a 4-byte-aligned address in one load (the hardware takes multi-dword global loads at
+// dword alignment): halves the number of load instructions of a 2x2 filter footprint.
+typedef uint32_t rdr_uint2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+RDR_DEV void load_pair(const RDR_GLOBAL uint32_t* p, uint32_t& a, uint32_t& b) {
+    const rdr_uint2_a4 v = *(const RDR_GLOBAL rdr_uint2_a4*)p;
+    a = v.x; b = v.y;
+}
 
 struct F3 { float x, y, z; };
 struct F4 { float x, y, z, w; };
@@ -311,7 +318,11 @@ RDR_DEV bool tex_same_geometry(const DTexDesc& x, const DTexDesc& y) {
 template <int MASK>
 RDR_DEV void tex_fetch_level(const float* srgb, const DTexDesc& t, const TexLevelTaps& k, float out[4]) {
     const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base);
-    const uint32_t q00 = px[k.o00], q10 = px[k.o10], q01 = px[k.o01], q11 = px[k.o11];
+    // the two texels of a row are neighbours in memory unless the footprint wraps around the edge
+    uint32_t q00, q10, q01, q11;
+    load_pair(px + k.o00, q00, q10);
+    load_pair(px + k.o01, q01, q11);
+    if (k.o10 != k.o00 + 1u) { q10 = px[k.o10]; q11 = px[k.o11]; }
     const bool is_srgb = ((t.info >> 5) & RDR_TEXD_SRGB) != 0u;
     const float a = k.a, b = k.b;
     float c00[4], c10[4], c01[4], c11[4];

@@ -297,7 +297,7 @@ int create_image(rdr_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h, bool s
         img.level_offset[l] = (uint32_t)texels;
         texels += (size_t)std::max(1u, w >> l) * std::max(1u, h >> l);
     }
-    HIP_TRY(img.pixels.ensure(texels * 4));
+    HIP_TRY(img.pixels.ensure(texels * 4 + 16));  // the shading kernels read texel pairs: one texel of slack after the last level
     HIP_TRY(hipMemcpyAsync(img.pixels.p, rgba, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream));
     const float* tables = c->d_tables.as<float>();
     for (uint32_t l = 1; l < levels; l++) {
