@@ -261,6 +261,14 @@ int rdr_set_environment_map(rdr_ctx* ctx, const float* const faces_rgba32f[6], u
  * (VulkanRenderer.cpp:44-45); here the caller hands over the decoded RGB(A)8
  * pixels, row 0 first. `channels` is 3 or 4. */
 int rdr_set_brdf_lut(rdr_ctx* ctx, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels);
+/* No counterpart in the reference, which is handed six decoded cube faces (main.cpp:434-441): converts an
+ * equirectangular RGBA32F panorama (row 0 = the +Y pole, column 0 = the -Z direction, u grows towards +X) into six
+ * face_res^2 faces by bilinear look-up (u wraps, v clamps), then does what rdr_set_environment_map does. */
+int rdr_set_environment_equirect(rdr_ctx* ctx, const float* rgba32f, uint32_t width, uint32_t height, uint32_t face_res);
+/* No counterpart in the reference, which ships the table as textures/ibl_brdf_lut.png: integrates the split-sum
+ * BRDF table (GGX importance sampling on the Hammersley points of envbakespecular.frag:17-53; R = scale, G = bias
+ * of F0) and installs it like rdr_set_brdf_lut. Layout as the shipped file: column = NdotV, row 0 = roughness 1. */
+int rdr_generate_brdf_lut(rdr_ctx* ctx, uint32_t size, uint32_t samples);
 /* renderer.camera() mutators (VulkanRenderer.h:108, Camera.h:35-54) collapsed
  * into one state upload. */
 int rdr_set_camera(rdr_ctx* ctx, const rdr_camera* camera);
@@ -309,6 +317,8 @@ int rdr_read_env_cube(rdr_ctx* ctx, int which /*0 env,1 irradiance,2 prefiltered
 /* 4 cascade matrices (64 floats) + 4 split depths of the last frame
  * (CSMSplitShaderData, VulkanRenderer.h:82-85). */
 int rdr_read_cascades(rdr_ctx* ctx, float* out_viewproj_4x16, float* out_depth_4);
+/* the installed BRDF table as RGBA8, row 0 first; out may be NULL to query the size. */
+int rdr_read_brdf_lut(rdr_ctx* ctx, uint8_t* out, uint32_t* out_w, uint32_t* out_h);
 /* mip `level` of image `image` as stored (RGBA8), for mip-chain parity. */
 int rdr_read_image_level(rdr_ctx* ctx, uint32_t image, uint32_t level, uint8_t* out, uint32_t* out_w, uint32_t* out_h);
 

@@ -502,6 +502,28 @@ int orc_set_environment_map(rdr_ctx* c, const float* const faces[6], uint32_t w,
     return RDR_OK;
 }
 
+int orc_set_environment_equirect(rdr_ctx* c, const float* pano, uint32_t w, uint32_t h, uint32_t face_res) {
+    if (!c || !pano || w == 0 || h == 0 || face_res == 0 || face_res > 8192) return fail(c, RDR_ERR_INVALID, "set_environment_equirect: bad argument");
+    equirect_to_cube(*c, pano, w, h, face_res);
+    bake_irradiance(*c);
+    bake_prefiltered(*c);
+    return RDR_OK;
+}
+
+int orc_generate_brdf_lut(rdr_ctx* c, uint32_t size, uint32_t samples) {
+    if (!c || size == 0 || size > 4096 || samples == 0 || samples > 65536) return fail(c, RDR_ERR_INVALID, "generate_brdf_lut: bad argument");
+    generate_brdf_lut(*c, size, samples);
+    return RDR_OK;
+}
+
+int orc_read_brdf_lut(rdr_ctx* c, uint8_t* out, uint32_t* ow, uint32_t* oh) {
+    if (!c || !c->lut_w) return fail(c, RDR_ERR_INVALID, "read_brdf_lut: no table");
+    if (ow) *ow = c->lut_w;
+    if (oh) *oh = c->lut_h;
+    if (out) std::memcpy(out, c->lut.data(), c->lut.size());
+    return RDR_OK;
+}
+
 int orc_set_brdf_lut(rdr_ctx* c, const uint8_t* px, uint32_t w, uint32_t h, uint32_t channels) {
     if (!c || !px || w == 0 || h == 0 || (channels != 3 && channels != 4)) return fail(c, RDR_ERR_INVALID, "set_brdf_lut: bad argument");
     c->lut_w = w; c->lut_h = h;

@@ -194,4 +194,110 @@ void bake_prefiltered(Ctx& c) {
     }
 }
 
+// ---- precompute steps the reference does not have (it is handed six decoded faces and ships its BRDF table as a
+// PNG): equirectangular panorama -> cube faces, and the split-sum BRDF table itself. Defined here so that the HIP
+// versions have something to be compared with; the table is pinned by the reference's textures/ibl_brdf_lut.png.
+
+// atan2 from + - * / and fma only (a 6-term odd polynomial on [0,1], |error| < 2e-5 rad), so that both
+// implementations produce the same bits; the library atan2f of the two sides do not.
+static inline float det_atan2(float y, float x) {
+    const float ax = std::fabs(x), ay = std::fabs(y);
+    const float mx = std::max(ax, ay), mn = std::min(ax, ay);
+    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    const float s = a * a;
+    float r = std::fmaf(s, -0.01172120f, 0.05265332f);
+    r = std::fmaf(s, r, -0.11643287f);
+    r = std::fmaf(s, r, 0.19354346f);
+    r = std::fmaf(s, r, -0.33262347f);
+    r = std::fmaf(s, r, 0.99997726f);
+    r = r * a;
+    if (ay > ax) r = 1.57079637f - r;
+    if (x < 0.0f) r = 3.14159274f - r;
+    return y < 0.0f ? -r : r;
+}
+
+// Direction through the centre of texel (i, j) of a cube face: the inverse of the Vulkan face-selection tables.
+static inline V3 face_texel_direction(int face, int i, int j, int res) {
+    const float sc = ((float)(2 * i + 1)) / (float)res - 1.0f, tc = ((float)(2 * j + 1)) / (float)res - 1.0f;
+    switch (face) {
+        case 0: return {1.0f, -tc, -sc};
+        case 1: return {-1.0f, -tc, sc};
+        case 2: return {sc, 1.0f, tc};
+        case 3: return {sc, -1.0f, -tc};
+        case 4: return {sc, -tc, 1.0f};
+        default: return {-sc, -tc, -1.0f};
+    }
+}
+
+// Panorama convention: u = atan2(x, -z) / 2pi + 1/2, v = angle from +Y / pi; bilinear, u wraps, v clamps.
+void equirect_to_cube(Ctx& c, const float* pano, uint32_t w, uint32_t h, uint32_t res) {
+    c.env.res = res; c.env.levels = 1;
+    c.env.level.assign(1, std::vector<uint32_t>((size_t)6 * res * res));
+    const int W = (int)w, H = (int)h;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int face = 0; face < 6; face++)
+        for (int j = 0; j < (int)res; j++)
+            for (int i = 0; i < (int)res; i++) {
+                const V3 d = face_texel_direction(face, i, j, (int)res);
+                const float u = det_atan2(d.x, -d.z) * 0.159154937f + 0.5f;
+                const float v = det_atan2(std::sqrt(d.x * d.x + d.z * d.z), d.y) * 0.318309873f;
+                const float tu = u * (float)W - 0.5f, tv = v * (float)H - 0.5f;
+                const float fu = std::floor(tu), fv = std::floor(tv);
+                const float a = tu - fu, b = tv - fv;
+                int i0 = (int)fu % W; if (i0 < 0) i0 += W;
+                const int i1 = (i0 + 1) % W;
+                const int j0 = std::min(std::max((int)fv, 0), H - 1), j1 = std::min(std::max((int)fv + 1, 0), H - 1);
+                float o[3];
+                for (int k = 0; k < 3; k++) {
+                    const float c00 = pano[((size_t)j0 * W + i0) * 4 + k], c10 = pano[((size_t)j0 * W + i1) * 4 + k];
+                    const float c01 = pano[((size_t)j1 * W + i0) * 4 + k], c11 = pano[((size_t)j1 * W + i1) * 4 + k];
+                    const float top = (1.0f - a) * c00 + a * c10, bot = (1.0f - a) * c01 + a * c11;
+                    o[k] = (1.0f - b) * top + b * bot;
+                }
+                c.env.level[0][((size_t)face * res + j) * res + i] = pack_r11g11b10(o[0], o[1], o[2]);
+            }
+}
+
+// Split-sum BRDF table (Karis 2013) on the Hammersley / GGX sampling helpers of envbakespecular.frag:17-53.
+// Texel (x, y): NdotV = (x + .5) / size, roughness = 1 - (y + .5) / size (row 0 = roughness 1, the orientation of
+// the reference's textures/ibl_brdf_lut.png as stored on disk). R = scale, G = bias of F0.
+void generate_brdf_lut(Ctx& c, uint32_t size, uint32_t samples) {
+    c.lut_w = c.lut_h = size;
+    c.lut.assign((size_t)size * size * 4, 0);
+    std::vector<float> cs(samples), sn(samples);
+    for (uint32_t s = 0; s < samples; s++) {
+        const float phi = 2.0f * 3.14159265359f * ((float)s / (float)samples);
+        cs[s] = std::cos(phi); sn[s] = std::sin(phi);
+    }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < (int)size; y++)
+        for (int x = 0; x < (int)size; x++) {
+            const float nv = ((float)x + 0.5f) / (float)size, rough = 1.0f - ((float)y + 0.5f) / (float)size;
+            const float a = rough * rough, k = a * 0.5f;
+            const float vx = std::sqrt(1.0f - nv * nv), vz = nv;
+            float A = 0.0f, Bc = 0.0f;
+            for (uint32_t s = 0; s < samples; s++) {
+                const float xi = radical_inverse(s);
+                const float ct = std::sqrt((1.0f - xi) / (1.0f + (a * a - 1.0f) * xi));
+                const float st = std::sqrt(1.0f - ct * ct);
+                const float hx = cs[s] * st, hz = ct;
+                float vdh = vx * hx + vz * hz;
+                const float lz = 2.0f * vdh * hz - vz;
+                const float ndl = std::min(std::max(lz, 0.0f), 1.0f), ndh = std::min(std::max(hz, 0.0f), 1.0f);
+                vdh = std::min(std::max(vdh, 0.0f), 1.0f);
+                if (ndl > 0.0f) {
+                    const float g = (ndl / (ndl * (1.0f - k) + k)) * (nv / (nv * (1.0f - k) + k));
+                    const float gv = g * vdh / std::max(ndh * nv, 1e-8f);
+                    const float om = 1.0f - vdh, om2 = om * om, fc = om2 * om2 * om;
+                    A += (1.0f - fc) * gv;
+                    Bc += fc * gv;
+                }
+            }
+            uint8_t* px = &c.lut[((size_t)y * size + x) * 4];
+            px[0] = float_to_unorm8(A / (float)samples);
+            px[1] = float_to_unorm8(Bc / (float)samples);
+            px[2] = 0; px[3] = 255;
+        }
+}
+
 }  // namespace orc

@@ -137,6 +137,8 @@ void shade_main(Ctx& c, const std::vector<Draw>& opaque, const std::vector<Draw>
 void bake_irradiance(Ctx& c);
 void bake_prefiltered(Ctx& c);
 void cube_sample(const Cube& cube, uint32_t level, float dx, float dy, float dz, float out[3]);
+void equirect_to_cube(Ctx& c, const float* pano, uint32_t w, uint32_t h, uint32_t res);
+void generate_brdf_lut(Ctx& c, uint32_t size, uint32_t samples);
 size_t cube_texel_offset(int face, int i, int j, int r);  // texel (i,j) of a face, one step outside folds over the cube edge
 // orc_tex.cpp
 void build_mips(Ctx& c, Image& img, uint32_t max_levels);

@@ -103,6 +103,9 @@ SIGNATURES = {
     "set_lights": (C.c_int, [_VP, C.POINTER(PointLight), C.c_uint32, C.POINTER(DirectionalLight)]),
     "set_environment_map": (C.c_int, [_VP, C.POINTER(_FP), C.c_uint32, C.c_uint32]),
     "set_brdf_lut": (C.c_int, [_VP, _U8P, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "set_environment_equirect": (C.c_int, [_VP, _FP, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "generate_brdf_lut": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    "read_brdf_lut": (C.c_int, [_VP, _U8P, _U32P, _U32P]),
     "set_camera": (C.c_int, [_VP, C.POINTER(Camera)]),
     "set_exposure_bias": (C.c_int, [_VP, C.c_float, C.c_float]),
     "render_frame": (C.c_int, [_VP, C.POINTER(FrameParams), _VP, C.c_int, _FP]),

@@ -164,8 +164,26 @@ class Renderer:
         """faces: array [6][res][res][4] float32, order +X,-X,+Y,-Y,+Z,-Z (main.cpp:434-441)."""
         f = B.as_f32(faces)
         assert f.ndim == 4 and f.shape[0] == 6 and f.shape[3] == 4
+        self._env_res = int(f.shape[1])
         ptrs = (B._FP * 6)(*[B.fptr(f[i]) for i in range(6)])
         self._check(self.api.set_environment_map(self._ctx, ptrs, f.shape[2], f.shape[1]), "set_environment_map")
+
+    def set_environment_equirect(self, panorama, face_res):
+        """panorama: [h][w][4] float32 equirectangular image; builds face_res^2 cube faces and runs the bakes."""
+        p = B.as_f32(panorama)
+        assert p.ndim == 3 and p.shape[2] == 4
+        self._env_res = int(face_res)
+        self._check(self.api.set_environment_equirect(self._ctx, B.fptr(p), p.shape[1], p.shape[0], int(face_res)), "set_environment_equirect")
+
+    def generate_brdf_lut(self, size=400, samples=1024):
+        self._check(self.api.generate_brdf_lut(self._ctx, int(size), int(samples)), "generate_brdf_lut")
+
+    def read_brdf_lut(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        self._check(self.api.read_brdf_lut(self._ctx, None, C.byref(w), C.byref(h)), "read_brdf_lut")
+        a = np.empty((h.value, w.value, 4), np.uint8)
+        self._check(self.api.read_brdf_lut(self._ctx, B.u8ptr(a), C.byref(w), C.byref(h)), "read_brdf_lut")
+        return a
 
     def set_brdf_lut(self, pixels):
         a = np.ascontiguousarray(pixels, dtype=np.uint8)

@@ -47,6 +47,8 @@ void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DVi
                          void* hdr);
 
 // kernels_ibl.hip
+void launch_equirect_to_cube(hipStream_t s, const void* pano_rgba32f, int w, int h, uint32_t* dst, int res);
+void launch_brdf_lut(hipStream_t s, uint32_t* dst, int size, int samples, const float* trig);
 void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n);
 void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb);
 void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig);

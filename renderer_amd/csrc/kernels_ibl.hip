@@ -151,8 +151,106 @@ __global__ void __launch_bounds__(256) k_mip_blit(const uint32_t* __restrict__ s
     dst[i] = o;
 }
 
+// ---- precompute steps with no counterpart in the reference (it receives six decoded faces and loads its BRDF table
+// from a PNG): panorama -> cube faces and the split-sum table.
+
+// atan2 from + - * / and fma only (6-term odd polynomial on [0,1], |error| < 2e-5 rad): the CPU checker evaluates
+// the same expression, so both produce the same bits.
+RDR_DEV float det_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    const float s = a * a;
+    float r = fmaf(s, -0.01172120f, 0.05265332f);
+    r = fmaf(s, r, -0.11643287f);
+    r = fmaf(s, r, 0.19354346f);
+    r = fmaf(s, r, -0.33262347f);
+    r = fmaf(s, r, 0.99997726f);
+    r = r * a;
+    if (ay > ax) r = 1.57079637f - r;
+    if (x < 0.0f) r = 3.14159274f - r;
+    return y < 0.0f ? -r : r;
+}
+
+// Direction through the centre of texel (i, j) of a face: the inverse of the face-selection tables of cube_face.
+RDR_DEV F3 face_texel_direction(int face, int i, int j, int res) {
+    const float sc = ((float)(2 * i + 1)) / (float)res - 1.0f, tc = ((float)(2 * j + 1)) / (float)res - 1.0f;
+    switch (face) {
+        case 0: return f3(1.0f, -tc, -sc);
+        case 1: return f3(-1.0f, -tc, sc);
+        case 2: return f3(sc, 1.0f, tc);
+        case 3: return f3(sc, -1.0f, -tc);
+        case 4: return f3(sc, -tc, 1.0f);
+        default: return f3(-sc, -tc, -1.0f);
+    }
+}
+
+// u = atan2(x, -z) / 2pi + 1/2, v = angle from +Y / pi; bilinear, u wraps, v clamps; writes packed texels
+__global__ void __launch_bounds__(256) k_equirect_to_cube(const float4* __restrict__ pano, int W, int H, uint32_t* __restrict__ dst, int res) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= 6u * res * res) return;
+    const int face = (int)(idx / (uint32_t)(res * res)), j = (int)((idx / (uint32_t)res) % (uint32_t)res), i = (int)(idx % (uint32_t)res);
+    const F3 d = face_texel_direction(face, i, j, res);
+    const float u = det_atan2(d.x, -d.z) * 0.159154937f + 0.5f;
+    const float v = det_atan2(sqrtf(d.x * d.x + d.z * d.z), d.y) * 0.318309873f;
+    const float tu = u * (float)W - 0.5f, tv = v * (float)H - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    int i0 = (int)fu % W; if (i0 < 0) i0 += W;
+    const int i1 = (i0 + 1) % W;
+    const int j0 = min(max((int)fv, 0), H - 1), j1 = min(max((int)fv + 1, 0), H - 1);
+    const float4 q00 = pano[(size_t)j0 * W + i0], q10 = pano[(size_t)j0 * W + i1];
+    const float4 q01 = pano[(size_t)j1 * W + i0], q11 = pano[(size_t)j1 * W + i1];
+    const float c00[3] = {q00.x, q00.y, q00.z}, c10[3] = {q10.x, q10.y, q10.z};
+    const float c01[3] = {q01.x, q01.y, q01.z}, c11[3] = {q11.x, q11.y, q11.z};
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float top = (1.0f - a) * c00[k] + a * c10[k], bot = (1.0f - a) * c01[k] + a * c11[k];
+        o[k] = (1.0f - b) * top + b * bot;
+    }
+    dst[idx] = pack_r11g11b10(o[0], o[1], o[2]);
+}
+
+// Split-sum BRDF table (Karis 2013) on the Hammersley / GGX helpers of envbakespecular.frag:17-53. Texel (x, y):
+// NdotV = (x + .5) / size, roughness = 1 - (y + .5) / size (row 0 = roughness 1, as textures/ibl_brdf_lut.png is
+// stored). `trig` = cos then sin of 2 pi s / samples. One lane per texel: the sums are in sample order.
+__global__ void __launch_bounds__(256) k_brdf_lut(uint32_t* __restrict__ dst, int size, int samples, const float* __restrict__ trig) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint32_t)(size * size)) return;
+    const int x = (int)(idx % (uint32_t)size), y = (int)(idx / (uint32_t)size);
+    const float nv = ((float)x + 0.5f) / (float)size, rough = 1.0f - ((float)y + 0.5f) / (float)size;
+    const float a = rough * rough, k = a * 0.5f;
+    const float vx = sqrtf(1.0f - nv * nv), vz = nv;
+    float A = 0.0f, B = 0.0f;
+    for (int s = 0; s < samples; s++) {
+        const float xi = radical_inverse((uint32_t)s);
+        const float ct = sqrtf((1.0f - xi) / (1.0f + (a * a - 1.0f) * xi));
+        const float st = sqrtf(1.0f - ct * ct);
+        const float hx = trig[s] * st, hz = ct;
+        float vdh = vx * hx + vz * hz;
+        const float lz = 2.0f * vdh * hz - vz;
+        const float ndl = fminf(fmaxf(lz, 0.0f), 1.0f), ndh = fminf(fmaxf(hz, 0.0f), 1.0f);
+        vdh = fminf(fmaxf(vdh, 0.0f), 1.0f);
+        if (ndl > 0.0f) {
+            const float g = (ndl / (ndl * (1.0f - k) + k)) * (nv / (nv * (1.0f - k) + k));
+            const float gv = g * vdh / fmaxf(ndh * nv, 1e-8f);
+            const float om = 1.0f - vdh, om2 = om * om, fc = om2 * om2 * om;
+            A += (1.0f - fc) * gv;
+            B += fc * gv;
+        }
+    }
+    dst[idx] = float_to_unorm8(A / (float)samples) | (float_to_unorm8(B / (float)samples) << 8) | 0xFF000000u;
+}
+
 }  // namespace
 
+void launch_equirect_to_cube(hipStream_t s, const void* pano_rgba32f, int w, int h, uint32_t* dst, int res) {
+    hipLaunchKernelGGL(k_equirect_to_cube, dim3((6u * res * res + 255) / 256), dim3(256), 0, s, (const float4*)pano_rgba32f, w, h, dst, res);
+}
+void launch_brdf_lut(hipStream_t s, uint32_t* dst, int size, int samples, const float* trig) {
+    hipLaunchKernelGGL(k_brdf_lut, dim3((size * size + 255) / 256), dim3(256), 0, s, dst, size, samples, trig);
+}
 void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n) {
     hipLaunchKernelGGL(k_env_pack, dim3((n + 255) / 256), dim3(256), 0, s, (const float4*)face_rgba32f, dst, n);
 }

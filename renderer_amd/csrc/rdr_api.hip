@@ -869,20 +869,8 @@ int rdr_set_lights(rdr_ctx* c, const rdr_point_light* lights, uint32_t count, co
     return RDR_OK;
 }
 
-int rdr_set_environment_map(rdr_ctx* c, const float* const faces[6], uint32_t w, uint32_t h) {
-    if (!c || !faces || w == 0 || w != h) return fail(c, RDR_ERR_INVALID, "set_environment_map: faces must be square");
-    for (int f = 0; f < 6; f++) if (!faces[f]) return fail(c, RDR_ERR_INVALID, "set_environment_map: null face");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t face_px = (size_t)w * w;
-    HIP_TRY(c->d_env.ensure(6 * face_px * 4));
-    DevBuf staging;
-    HIP_TRY(staging.ensure(face_px * 16));
-    for (int f = 0; f < 6; f++) {
-        HIP_TRY(hipMemcpyAsync(staging.p, faces[f], face_px * 16, hipMemcpyHostToDevice, c->stream));
-        launch_env_pack(c->stream, staging.p, c->d_env.as<uint32_t>() + f * face_px, (uint32_t)face_px);
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    staging.release();
+// Both bakes from the packed cube in d_env (the second half of setEnvironmentMap).
+static int bake_environment(rdr_ctx* c, uint32_t w) {
     memset(&c->env, 0, sizeof c->env);
     c->env.texels = c->d_env.as<uint32_t>(); c->env.res = w; c->env.levels = 1;
     // irradiance: 256^2 per face (VulkanRenderer.h:220)
@@ -923,6 +911,69 @@ int rdr_set_environment_map(rdr_ctx* c, const float* const faces[6], uint32_t w,
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
+    return RDR_OK;
+}
+
+int rdr_set_environment_map(rdr_ctx* c, const float* const faces[6], uint32_t w, uint32_t h) {
+    if (!c || !faces || w == 0 || w != h) return fail(c, RDR_ERR_INVALID, "set_environment_map: faces must be square");
+    for (int f = 0; f < 6; f++) if (!faces[f]) return fail(c, RDR_ERR_INVALID, "set_environment_map: null face");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t face_px = (size_t)w * w;
+    HIP_TRY(c->d_env.ensure(6 * face_px * 4));
+    DevBuf staging;
+    HIP_TRY(staging.ensure(face_px * 16));
+    for (int f = 0; f < 6; f++) {
+        HIP_TRY(hipMemcpyAsync(staging.p, faces[f], face_px * 16, hipMemcpyHostToDevice, c->stream));
+        launch_env_pack(c->stream, staging.p, c->d_env.as<uint32_t>() + f * face_px, (uint32_t)face_px);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    staging.release();
+    return bake_environment(c, w);
+}
+
+int rdr_set_environment_equirect(rdr_ctx* c, const float* pano, uint32_t w, uint32_t h, uint32_t face_res) {
+    if (!c || !pano || w == 0 || h == 0 || w > 32768 || h > 32768 || face_res == 0 || face_res > 8192)
+        return fail(c, RDR_ERR_INVALID, "set_environment_equirect: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->d_env.ensure((size_t)6 * face_res * face_res * 4));
+    DevBuf staging;
+    HIP_TRY(staging.ensure((size_t)w * h * 16));
+    HIP_TRY(hipMemcpyAsync(staging.p, pano, (size_t)w * h * 16, hipMemcpyHostToDevice, c->stream));
+    launch_equirect_to_cube(c->stream, staging.p, (int)w, (int)h, c->d_env.as<uint32_t>(), (int)face_res);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    staging.release();
+    return bake_environment(c, face_res);
+}
+
+int rdr_generate_brdf_lut(rdr_ctx* c, uint32_t size, uint32_t samples) {
+    if (!c || size == 0 || size > 4096 || samples == 0 || samples > 65536) return fail(c, RDR_ERR_INVALID, "generate_brdf_lut: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float> trig(2 * (size_t)samples);
+    for (uint32_t s = 0; s < samples; s++) {
+        const float phi = 2.0f * 3.14159265359f * ((float)s / (float)samples);
+        trig[s] = cosf(phi); trig[samples + s] = sinf(phi);
+    }
+    DevBuf d_trig;
+    HIP_TRY(d_trig.ensure(trig.size() * 4));
+    HIP_TRY(hipMemcpyAsync(d_trig.p, trig.data(), trig.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c->d_lut.ensure((size_t)size * size * 4));
+    launch_brdf_lut(c->stream, c->d_lut.as<uint32_t>(), (int)size, (int)samples, d_trig.as<float>());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    d_trig.release();
+    c->lut_w = c->lut_h = size;
+    return RDR_OK;
+}
+
+int rdr_read_brdf_lut(rdr_ctx* c, uint8_t* out, uint32_t* ow, uint32_t* oh) {
+    if (!c || !c->lut_w) return fail(c, RDR_ERR_INVALID, "read_brdf_lut: no table");
+    if (ow) *ow = c->lut_w;
+    if (oh) *oh = c->lut_h;
+    if (out) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(out, c->d_lut.p, (size_t)c->lut_w * c->lut_h * 4, hipMemcpyDeviceToHost));
+    }
     return RDR_OK;
 }
 
