@@ -5,7 +5,7 @@
  * the private half of `class VulkanRenderer`. The seam this library cuts is
  * that class's PUBLIC surface (Renderer/VulkanRenderer.h:94-110). Every entry
  * point below names the reference member it stands in for. The C++ façade in
- * renderer_amd/host/ re-creates the reference's own class names on top of it.
+ * include/renderer.hpp re-creates the reference's own class names on top of it.
  *
  * Conventions
  *  - plain C types only; no exceptions cross the boundary; every call returns
@@ -92,6 +92,8 @@ enum rdr_attribute_name {
     RDR_ATTR_TANGENT = 2,    /* "TANGENT"    vec4 float (w = handedness) */
     RDR_ATTR_TEXCOORD_0 = 3, /* "TEXCOORD_0" vec2 float / unorm8 / unorm16 */
     RDR_ATTR_BITANGENT = 4,  /* legacy interleaved Vertex only (Vertex.h:11) */
+    RDR_ATTR_JOINTS_0 = 5,   /* "JOINTS_0"   vec4 uint8 / uint16; not read by the reference (main.cpp:61-177) */
+    RDR_ATTR_WEIGHTS_0 = 6,  /* "WEIGHTS_0"  vec4 float / unorm8 / unorm16; a primitive with both is skinned */
 };
 typedef struct rdr_vertex_attribute {
     uint32_t name;      /* rdr_attribute_name */
@@ -248,6 +250,15 @@ int rdr_add_mesh(rdr_ctx* ctx, const rdr_primitive_desc* primitives, uint32_t co
 /* drawMeshes reads mesh->node->modelMatrix() every frame
  * (VulkanRenderer.cpp:975); this is how a caller moves a node. */
 int rdr_set_mesh_transform(rdr_ctx* ctx, uint32_t mesh_id, const float model[16]);
+/* No counterpart in the reference, which has node animation only (Node.cpp:21-38) and reads no skins. Sets the
+ * joint-matrix palette of a mesh whose primitives carry JOINTS_0 + WEIGHTS_0: `count` column-major 4x4 matrices in
+ * the mesh's model space (glTF: inverse(meshGlobal) * jointGlobal * inverseBind). Before the next frame every vertex
+ * becomes S * rest with S = w0*J[j0] + w1*J[j1] + w2*J[j2] + w3*J[j3] (positions with w = 1; normal, tangent and
+ * bitangent by the upper 3x3, as the vertex stage treats `model`, basic.vert:41-44); the mesh's model matrix applies
+ * afterwards as usual. The culling box of each primitive becomes the box around its rest box carried by every joint.
+ * `count` must cover the largest joint index in use; the mesh must have been added with is_static == 0. Until the
+ * first call the palette is the identity (rest pose). */
+int rdr_set_mesh_joints(rdr_ctx* ctx, uint32_t mesh_id, const float* joint_matrices, uint32_t count);
 /* VulkanRenderer::setLights (VulkanRenderer.cpp:204-246). Also fixes the PSSM
  * cascade splits from the camera's near/far AT THIS MOMENT
  * (VulkanRendererShadow.cpp:152-175). */
@@ -317,6 +328,9 @@ int rdr_read_env_cube(rdr_ctx* ctx, int which /*0 env,1 irradiance,2 prefiltered
 /* 4 cascade matrices (64 floats) + 4 split depths of the last frame
  * (CSMSplitShaderData, VulkanRenderer.h:82-85). */
 int rdr_read_cascades(rdr_ctx* ctx, float* out_viewproj_4x16, float* out_depth_4);
+/* model-space positions of primitive `primitive` of mesh `mesh_id` as the next frame will rasterise them (after
+ * skinning): count*3 floats; out may be NULL to query the count. */
+int rdr_read_primitive_positions(rdr_ctx* ctx, uint32_t mesh_id, uint32_t primitive, float* out_xyz, uint32_t* out_count);
 /* the installed BRDF table as RGBA8, row 0 first; out may be NULL to query the size. */
 int rdr_read_brdf_lut(rdr_ctx* ctx, uint8_t* out, uint32_t* out_w, uint32_t* out_h);
 /* mip `level` of image `image` as stored (RGBA8), for mip-chain parity. */

@@ -421,6 +421,16 @@ public:
     void setBrdfLut(const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels) {
         check(RDR_ABI(set_brdf_lut)(ctx, pixels, width, height, channels), "setBrdfLut");
     }
+    // No counterpart in the reference (main.cpp:434-441 decodes six face files): an equirectangular RGBA32F panorama is
+    // resampled to faceRes^2 cube faces on the GPU, then baked as setEnvironmentMap does.
+    void setEnvironmentPanorama(const TextureInfo& panorama, uint32_t faceRes) {
+        if (panorama.data.size() < (size_t)panorama.width * panorama.height * 16)
+            throw std::runtime_error("setEnvironmentPanorama: the panorama must be an RGBA32F image");
+        check(RDR_ABI(set_environment_equirect)(ctx, reinterpret_cast<const float*>(panorama.data.data()), panorama.width, panorama.height, faceRes),
+              "setEnvironmentPanorama");
+    }
+    // Builds the table that textures/ibl_brdf_lut.png holds instead of loading it.
+    void generateBrdfLut(uint32_t size = 400, uint32_t samples = 1024) { check(RDR_ABI(generate_brdf_lut)(ctx, size, samples), "generateBrdfLut"); }
     void setLights(const std::vector<PointLight>& pointLights, const DirectionalLight& d) {
         std::vector<rdr_point_light> pl(pointLights.size());
         for (size_t i = 0; i < pl.size(); i++) {

@@ -367,10 +367,10 @@ int orc_add_mesh(rdr_ctx* c, const rdr_primitive_desc* prims, uint32_t count, co
     for (uint32_t pi = 0; pi < count; pi++) {
         const rdr_primitive_desc& d = prims[pi];
         if (d.mode != 4) return fail(c, RDR_ERR_UNSUPPORTED, "add_mesh: only triangle lists are supported");
-        const rdr_vertex_attribute* at[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const rdr_vertex_attribute* at[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (uint32_t a = 0; a < d.attribute_count; a++) {
             const rdr_vertex_attribute& va = d.attributes[a];
-            if (va.name > RDR_ATTR_BITANGENT) continue;
+            if (va.name > RDR_ATTR_WEIGHTS_0) continue;
             if (va.buffer >= c->buffers.size()) return fail(c, RDR_ERR_INVALID, "add_mesh: bad buffer id");
             at[va.name] = &va;
         }
@@ -385,7 +385,7 @@ int orc_add_mesh(rdr_ctx* c, const rdr_primitive_desc* prims, uint32_t count, co
             const size_t off = (size_t)va->offset + i * stride;
             const std::vector<uint8_t>& buf = c->buffers[va->buffer];
             if (off + vs * std::min(comps, have) > buf.size()) return false;
-            const bool norm = va->name == RDR_ATTR_TEXCOORD_0 && va->value_type != RDR_FLOAT;
+            const bool norm = (va->name == RDR_ATTR_TEXCOORD_0 || va->name == RDR_ATTR_WEIGHTS_0) && va->value_type != RDR_FLOAT;
             for (int k = 0; k < comps; k++) o[k] = k < have ? read_as_float(&buf[off + k * vs], va->value_type, norm) : 0.0f;
             return true;
         };
@@ -456,6 +456,24 @@ int orc_add_mesh(rdr_ctx* c, const rdr_primitive_desc* prims, uint32_t count, co
         for (uint32_t t : tex_ids)
             if (t != RDR_INVALID_ID && t >= c->textures.size()) return fail(c, RDR_ERR_INVALID, "add_mesh: bad texture id");
         p.mesh = mesh_id;
+        if (at[RDR_ATTR_JOINTS_0] && at[RDR_ATTR_WEIGHTS_0]) {
+            const uint32_t jt = at[RDR_ATTR_JOINTS_0]->value_type;
+            if (jt != RDR_UINT8 && jt != RDR_UINT16) return fail(c, RDR_ERR_UNSUPPORTED, "add_mesh: JOINTS_0 must be uint8 or uint16");
+            if (mesh.is_static) return fail(c, RDR_ERR_INVALID, "add_mesh: a skinned mesh must be added with is_static = 0");
+            p.skinned = true;
+            p.joints.resize(nv * 4); p.weights.resize(nv * 4);
+            for (size_t i = 0; i < nv; i++) {
+                float j[4], w[4];
+                if (!fetch(at[RDR_ATTR_JOINTS_0], i, 4, j) || !fetch(at[RDR_ATTR_WEIGHTS_0], i, 4, w))
+                    return fail(c, RDR_ERR_INVALID, "add_mesh: JOINTS_0 / WEIGHTS_0 out of range");
+                for (int k = 0; k < 4; k++) {
+                    p.joints[i * 4 + k] = (uint16_t)j[k]; p.weights[i * 4 + k] = w[k];
+                    mesh.n_joints = std::max(mesh.n_joints, (uint32_t)p.joints[i * 4 + k] + 1);
+                }
+            }
+            p.rest_pos = p.pos; p.rest_attr = p.attr;
+            p.rest_bb_min = p.bb_min; p.rest_bb_max = p.bb_max;
+        }
         built.push_back(std::move(p));
     }
     for (auto& p : built) c->prims.push_back(std::move(p));
@@ -467,6 +485,62 @@ int orc_add_mesh(rdr_ctx* c, const rdr_primitive_desc* prims, uint32_t count, co
 int orc_set_mesh_transform(rdr_ctx* c, uint32_t mesh_id, const float model[16]) {
     if (!c || !model || mesh_id >= c->meshes.size()) return fail(c, RDR_ERR_INVALID, "set_mesh_transform: bad argument");
     std::memcpy(c->meshes[mesh_id].model.c, model, 64);
+    return RDR_OK;
+}
+
+// Linear-blend skinning, evaluated in this fixed order so that the HIP kernel can match it bit for bit:
+// S = ((w0*J0 + w1*J1) + w2*J2) + w3*J3 element-wise on the three affine rows, then row . (x, y, z[, 1]).
+int orc_set_mesh_joints(rdr_ctx* c, uint32_t mesh_id, const float* jm, uint32_t count) {
+    if (!c || !jm || mesh_id >= c->meshes.size()) return fail(c, RDR_ERR_INVALID, "set_mesh_joints: bad argument");
+    Mesh& mesh = c->meshes[mesh_id];
+    if (mesh.n_joints == 0) return fail(c, RDR_ERR_INVALID, "set_mesh_joints: the mesh has no skinned primitive");
+    if (count < mesh.n_joints) return fail(c, RDR_ERR_INVALID, "set_mesh_joints: fewer matrices than the largest joint index in use");
+    for (uint32_t pi = mesh.first_prim; pi < mesh.first_prim + mesh.prim_count; pi++) {
+        Primitive& p = c->prims[pi];
+        if (!p.skinned) continue;
+        const size_t nv = p.rest_pos.size();
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < (long long)nv; i++) {
+            const uint16_t* j = &p.joints[i * 4];
+            const float* w = &p.weights[i * 4];
+            float S[3][4];  // S[row][col]
+            for (int r = 0; r < 3; r++)
+                for (int col = 0; col < 4; col++) {
+                    const int e = col * 4 + r;
+                    S[r][col] = ((w[0] * jm[j[0] * 16 + e] + w[1] * jm[j[1] * 16 + e]) + w[2] * jm[j[2] * 16 + e]) + w[3] * jm[j[3] * 16 + e];
+                }
+            auto point = [&](V3 v) { return v3(((S[0][0] * v.x + S[0][1] * v.y) + S[0][2] * v.z) + S[0][3], ((S[1][0] * v.x + S[1][1] * v.y) + S[1][2] * v.z) + S[1][3],
+                                               ((S[2][0] * v.x + S[2][1] * v.y) + S[2][2] * v.z) + S[2][3]); };
+            auto dir = [&](V3 v) { return v3((S[0][0] * v.x + S[0][1] * v.y) + S[0][2] * v.z, (S[1][0] * v.x + S[1][1] * v.y) + S[1][2] * v.z,
+                                             (S[2][0] * v.x + S[2][1] * v.y) + S[2][2] * v.z); };
+            p.pos[i] = point(p.rest_pos[i]);
+            p.attr[i].normal = dir(p.rest_attr[i].normal);
+            p.attr[i].tangent = dir(p.rest_attr[i].tangent);
+            p.attr[i].bitangent = dir(p.rest_attr[i].bitangent);
+        }
+        // culling box: around the rest box carried by every joint (a vertex is a convex combination of those images)
+        V3 lo = v3(INFINITY, INFINITY, INFINITY), hi = v3(-INFINITY, -INFINITY, -INFINITY);
+        for (uint32_t jn = 0; jn < mesh.n_joints; jn++) {
+            const float* m = jm + (size_t)jn * 16;
+            for (int k = 0; k < 8; k++) {
+                const float x = (k & 1) ? p.rest_bb_max.x : p.rest_bb_min.x, y = (k & 2) ? p.rest_bb_max.y : p.rest_bb_min.y,
+                            z = (k & 4) ? p.rest_bb_max.z : p.rest_bb_min.z;
+                const float qx = ((m[0] * x + m[4] * y) + m[8] * z) + m[12], qy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13],
+                            qz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+                lo = v3(std::min(lo.x, qx), std::min(lo.y, qy), std::min(lo.z, qz));
+                hi = v3(std::max(hi.x, qx), std::max(hi.y, qy), std::max(hi.z, qz));
+            }
+        }
+        p.bb_min = lo; p.bb_max = hi;
+    }
+    return RDR_OK;
+}
+
+int orc_read_primitive_positions(rdr_ctx* c, uint32_t mesh_id, uint32_t primitive, float* out, uint32_t* out_count) {
+    if (!c || mesh_id >= c->meshes.size() || primitive >= c->meshes[mesh_id].prim_count) return fail(c, RDR_ERR_INVALID, "read_primitive_positions: bad id");
+    const Primitive& p = c->prims[c->meshes[mesh_id].first_prim + primitive];
+    if (out_count) *out_count = (uint32_t)p.pos.size();
+    if (out) for (size_t i = 0; i < p.pos.size(); i++) { out[i * 3] = p.pos[i].x; out[i * 3 + 1] = p.pos[i].y; out[i * 3 + 2] = p.pos[i].z; }
     return RDR_OK;
 }
 

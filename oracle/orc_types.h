@@ -38,11 +38,19 @@ struct Primitive {
     V3 barycenter;  // world space, fixed at load (Renderer/Mesh.cpp:77-86)
     rdr_material mat;
     uint32_t mesh;
+    // skinned primitives keep their rest pose; pos/attr/bb_* above then hold the current pose
+    bool skinned = false;
+    std::vector<V3> rest_pos;
+    std::vector<VertexAttr> rest_attr;
+    std::vector<uint16_t> joints;  // 4 per vertex
+    std::vector<float> weights;    // 4 per vertex
+    V3 rest_bb_min, rest_bb_max;
 };
 struct Mesh {
     M4 model;
     bool is_static;
     uint32_t first_prim, prim_count;
+    uint32_t n_joints = 0;  // largest joint index in use + 1; 0 = not skinned
 };
 struct Camera {  // Renderer/Camera.h:61-82
     int type = RDR_CAMERA_PERSPECTIVE;

@@ -16,7 +16,7 @@ FORMAT_R8G8B8_UNORM, FORMAT_R8G8B8_SRGB, FORMAT_R8G8B8A8_UNORM, FORMAT_R8G8B8A8_
 # enum rdr_value_type / rdr_container_type (Renderer/Mesh.h:12-52)
 INT8, INT16, INT32, INT64, UINT8, UINT16, UINT32, UINT64, HALF, FLOAT, DOUBLE = range(11)
 SCALAR, VEC2, VEC3, VEC4 = range(4)
-ATTR_POSITION, ATTR_NORMAL, ATTR_TANGENT, ATTR_TEXCOORD_0, ATTR_BITANGENT = range(5)
+ATTR_POSITION, ATTR_NORMAL, ATTR_TANGENT, ATTR_TEXCOORD_0, ATTR_BITANGENT, ATTR_JOINTS_0, ATTR_WEIGHTS_0 = range(7)
 ALPHA_OPAQUE, ALPHA_MASK, ALPHA_BLEND = 0, 1, 2
 CAMERA_PERSPECTIVE, CAMERA_ORTHOGRAPHIC = 0, 1
 POINT_LIGHT_CAST_SHADOWS, POINT_LIGHT_HAS_SHADOW_MAP, POINT_LIGHT_STATIC_SHADOW_MAP_RENDERED = 1, 2, 4
@@ -100,11 +100,13 @@ SIGNATURES = {
     "make_texture": (C.c_int, [_VP, C.c_uint32, C.POINTER(Sampler), _U32P]),
     "add_mesh": (C.c_int, [_VP, C.POINTER(PrimitiveDesc), C.c_uint32, _FP, C.c_int, _U32P]),
     "set_mesh_transform": (C.c_int, [_VP, C.c_uint32, _FP]),
+    "set_mesh_joints": (C.c_int, [_VP, C.c_uint32, _FP, C.c_uint32]),
     "set_lights": (C.c_int, [_VP, C.POINTER(PointLight), C.c_uint32, C.POINTER(DirectionalLight)]),
     "set_environment_map": (C.c_int, [_VP, C.POINTER(_FP), C.c_uint32, C.c_uint32]),
     "set_brdf_lut": (C.c_int, [_VP, _U8P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "set_environment_equirect": (C.c_int, [_VP, _FP, C.c_uint32, C.c_uint32, C.c_uint32]),
     "generate_brdf_lut": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    "read_primitive_positions": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _FP, _U32P]),
     "read_brdf_lut": (C.c_int, [_VP, _U8P, _U32P, _U32P]),
     "set_camera": (C.c_int, [_VP, C.POINTER(Camera)]),
     "set_exposure_bias": (C.c_int, [_VP, C.c_float, C.c_float]),

@@ -146,6 +146,19 @@ class Renderer:
         m = B.as_f32(model).reshape(16)
         self._check(self.api.set_mesh_transform(self._ctx, mesh_id, B.fptr(m)), "set_mesh_transform")
 
+    def set_mesh_joints(self, mesh_id, joint_matrices):
+        """joint_matrices: [n][4][4], each laid out like `model` in add_mesh (flattening gives column-major, i.e.
+        the transpose of the numpy math-convention matrix)."""
+        j = B.as_f32(joint_matrices).reshape(-1)
+        self._check(self.api.set_mesh_joints(self._ctx, mesh_id, B.fptr(j), j.size // 16), "set_mesh_joints")
+
+    def read_primitive_positions(self, mesh_id, primitive):
+        n = C.c_uint32()
+        self._check(self.api.read_primitive_positions(self._ctx, mesh_id, primitive, None, C.byref(n)), "read_primitive_positions")
+        a = np.empty((n.value, 3), np.float32)
+        self._check(self.api.read_primitive_positions(self._ctx, mesh_id, primitive, B.fptr(a), C.byref(n)), "read_primitive_positions")
+        return a
+
     def set_lights(self, point_lights, directional):
         """point_lights: list of (point3, intensity3, cast_shadows); directional: (position3, intensity3, quat_wxyz)."""
         n = len(point_lights)

@@ -47,6 +47,9 @@ void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DVi
                          void* hdr);
 
 // kernels_ibl.hip
+// per-frame skinning of the vertex arena (kernels_skin.hip): rest pose + joints/weights + palette -> pos/attr
+void launch_skin(hipStream_t s, const void* rest_pos, const void* rest_attr, const void* joints, const void* weights, const void* dst_pal,
+                 const float* palette, void* pos, void* attr, uint32_t n);
 void launch_equirect_to_cube(hipStream_t s, const void* pano_rgba32f, int w, int h, uint32_t* dst, int res);
 void launch_brdf_lut(hipStream_t s, uint32_t* dst, int size, int samples, const float* trig);
 void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n);

@@ -73,8 +73,17 @@ struct HostPrim {
     vec3 bb_min, bb_max, barycenter;
     rdr_material mat;
     uint32_t mesh;
+    bool skinned = false;
+    uint32_t skin_first = 0;  // first entry of this primitive in the skin arrays
+    vec3 rest_bb_min, rest_bb_max;
 };
-struct HostMesh { mat4 model; bool is_static; };
+struct HostMesh {
+    mat4 model; bool is_static;
+    uint32_t first_prim = 0, prim_count = 0;
+    uint32_t n_joints = 0;       // largest joint index in use + 1; 0 = not skinned
+    uint32_t palette_base = 0;   // first matrix of this mesh in the frame's palette
+    std::vector<float> joints;   // n_joints x 16, column-major; identity until rdr_set_mesh_joints
+};
 struct HostLight { vec3 point, intensity; uint32_t flags; uint16_t slot; };
 
 struct Batch {
@@ -100,7 +109,11 @@ struct rdr_ctx {
     std::vector<float> h_pos;          // float4 per vertex
     std::vector<DVertexAttr> h_attr;
     std::vector<uint32_t> h_idx;
-    bool geometry_dirty = true, textures_dirty = true;
+    // skinned vertices: arena index + owning mesh, joints (4 x u16) and weights (4 x f32); the arena keeps the rest pose on the host
+    std::vector<uint32_t> h_skin_dst, h_skin_mesh, h_skin_joints;
+    std::vector<float> h_skin_weights;
+    uint32_t palette_matrices = 0;
+    bool geometry_dirty = true, textures_dirty = true, skin_dirty = false;
     Camera camera;
     std::vector<HostLight> lights;
     rdr_directional_light dir_light;
@@ -110,6 +123,8 @@ struct rdr_ctx {
 
     // scene, device side
     DevBuf d_pos, d_attr, d_idx, d_prims, d_textures, d_lights, d_tables, d_trig;
+    DevBuf d_rest_pos, d_rest_attr, d_skin_joints, d_skin_weights, d_skin_dst_pal, d_palette;
+    PinBuf h_palette;
     DevBuf d_env, d_irradiance, d_prefiltered, d_lut;
     DCube env{}, irradiance{}, prefiltered{};
     uint32_t lut_w = 0, lut_h = 0;
@@ -238,6 +253,24 @@ float component_as_float(const uint8_t* p, uint32_t value_type, bool normalized)
     }
 }
 
+// Re-poses the skinned vertices of the arena from the current palettes (enqueued on the context's stream).
+int run_skinning(rdr_ctx* c) {
+    const size_t ns = c->h_skin_dst.size();
+    if (!ns || !c->skin_dirty) return RDR_OK;
+    const size_t bytes = (size_t)c->palette_matrices * 64;
+    // the pinned block is free to rewrite: every caller synchronises the stream after this copy and before it can
+    // come back here (the frame does when it reads the pair count back, the read-back before its copy)
+    HIP_TRY(c->h_palette.ensure(bytes));
+    HIP_TRY(c->d_palette.ensure(bytes));
+    for (const HostMesh& m : c->meshes)
+        if (m.n_joints) memcpy(c->h_palette.as<float>() + (size_t)m.palette_base * 16, m.joints.data(), (size_t)m.n_joints * 64);
+    HIP_TRY(hipMemcpyAsync(c->d_palette.p, c->h_palette.p, bytes, hipMemcpyHostToDevice, c->stream));
+    launch_skin(c->stream, c->d_rest_pos.p, c->d_rest_attr.p, c->d_skin_joints.p, c->d_skin_weights.p, c->d_skin_dst_pal.p, c->d_palette.as<float>(),
+                c->d_pos.p, c->d_attr.p, (uint32_t)ns);
+    c->skin_dirty = false;
+    return RDR_OK;
+}
+
 int upload_scene(rdr_ctx* c) {
     if (c->geometry_dirty) {
         HIP_TRY(c->d_pos.ensure(std::max<size_t>(c->h_pos.size() * 4, 16)));
@@ -263,6 +296,33 @@ int upload_scene(rdr_ctx* c) {
         }
         HIP_TRY(c->d_prims.ensure(dp.size() * sizeof(DPrim)));
         HIP_TRY(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+        const size_t ns = c->h_skin_dst.size();
+        if (ns) {
+            // rest pose of the skinned vertices, gathered from the arena; palette slots in mesh order
+            uint32_t base = 0;
+            for (HostMesh& m : c->meshes) { m.palette_base = base; base += m.n_joints; }
+            c->palette_matrices = base;
+            std::vector<float> rp(ns * 4);
+            std::vector<DVertexAttr> ra(ns);
+            std::vector<uint32_t> dst_pal(ns * 2);
+            for (size_t i = 0; i < ns; i++) {
+                const uint32_t v = c->h_skin_dst[i];
+                memcpy(&rp[i * 4], &c->h_pos[(size_t)v * 4], 16);
+                ra[i] = c->h_attr[v];
+                dst_pal[i * 2] = v; dst_pal[i * 2 + 1] = c->meshes[c->h_skin_mesh[i]].palette_base;
+            }
+            HIP_TRY(c->d_rest_pos.ensure(ns * 16));
+            HIP_TRY(c->d_rest_attr.ensure(ns * sizeof(DVertexAttr)));
+            HIP_TRY(c->d_skin_joints.ensure(ns * 8));
+            HIP_TRY(c->d_skin_weights.ensure(ns * 16));
+            HIP_TRY(c->d_skin_dst_pal.ensure(ns * 8));
+            HIP_TRY(hipMemcpy(c->d_rest_pos.p, rp.data(), ns * 16, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_rest_attr.p, ra.data(), ns * sizeof(DVertexAttr), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_skin_joints.p, c->h_skin_joints.data(), ns * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_skin_weights.p, c->h_skin_weights.data(), ns * 16, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_skin_dst_pal.p, dst_pal.data(), ns * 8, hipMemcpyHostToDevice));
+            c->skin_dirty = true;
+        }
         c->geometry_dirty = false;
     }
     if (c->textures_dirty) {
@@ -659,10 +719,11 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_views, &c->d_draws,
                       &c->d_draw_first, &c->d_first_tri, &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start, &c->d_tile_end,
-                      &c->d_counters, &c->d_frame, &c->d_shade_tris, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
+                      &c->d_counters, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
-    c->h_stage.release(); c->h_read.release();
+    c->h_stage.release(); c->h_read.release(); c->h_palette.release();
     for (int i = 0; i < 10; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -716,19 +777,22 @@ int rdr_add_mesh(rdr_ctx* c, const rdr_primitive_desc* descs, uint32_t count, co
     HostMesh mesh;
     memcpy(mesh.model.m, model, 64);
     mesh.is_static = is_static != 0;
+    mesh.first_prim = (uint32_t)c->prims.size(); mesh.prim_count = count;
     const uint32_t mesh_id = (uint32_t)c->meshes.size();
     const size_t keep_pos = c->h_pos.size(), keep_attr = c->h_attr.size(), keep_idx = c->h_idx.size(), keep_prims = c->prims.size();
+    const size_t keep_skin = c->h_skin_dst.size();
     auto rollback = [&](int code, const char* msg) {
         c->h_pos.resize(keep_pos); c->h_attr.resize(keep_attr); c->h_idx.resize(keep_idx); c->prims.resize(keep_prims);
+        c->h_skin_dst.resize(keep_skin); c->h_skin_mesh.resize(keep_skin); c->h_skin_joints.resize(keep_skin * 2); c->h_skin_weights.resize(keep_skin * 4);
         return fail(c, code, msg);
     };
     for (uint32_t pi = 0; pi < count; pi++) {
         const rdr_primitive_desc& d = descs[pi];
         if (d.mode != 4) return rollback(RDR_ERR_UNSUPPORTED, "add_mesh: only triangle lists are supported");
-        const rdr_vertex_attribute* at[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const rdr_vertex_attribute* at[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (uint32_t a = 0; a < d.attribute_count; a++) {
             const rdr_vertex_attribute& va = d.attributes[a];
-            if (va.name > RDR_ATTR_BITANGENT) continue;
+            if (va.name > RDR_ATTR_WEIGHTS_0) continue;
             if (va.buffer >= c->buffers.size()) return rollback(RDR_ERR_INVALID, "add_mesh: bad buffer id");
             at[va.name] = &va;
         }
@@ -751,7 +815,7 @@ int rdr_add_mesh(rdr_ctx* c, const rdr_primitive_desc* descs, uint32_t count, co
             const size_t off = (size_t)va->offset + i * stride;
             const std::vector<uint8_t>& buf = c->buffers[va->buffer];
             if (off + vs * std::min(comps, have) > buf.size()) return false;
-            const bool norm = va->name == RDR_ATTR_TEXCOORD_0 && va->value_type != RDR_FLOAT;
+            const bool norm = (va->name == RDR_ATTR_TEXCOORD_0 || va->name == RDR_ATTR_WEIGHTS_0) && va->value_type != RDR_FLOAT;
             for (int k = 0; k < comps; k++) o[k] = k < have ? component_as_float(&buf[off + k * vs], va->value_type, norm) : 0.0f;
             return true;
         };
@@ -838,8 +902,30 @@ int rdr_add_mesh(rdr_ctx* c, const rdr_primitive_desc* descs, uint32_t count, co
         for (uint32_t t : tex_ids)
             if (t != RDR_INVALID_ID && t >= c->textures.size()) return rollback(RDR_ERR_INVALID, "add_mesh: bad texture id");
         hp.mesh = mesh_id;
+        if (at[RDR_ATTR_JOINTS_0] && at[RDR_ATTR_WEIGHTS_0]) {
+            const uint32_t jt = at[RDR_ATTR_JOINTS_0]->value_type;
+            if (jt != RDR_UINT8 && jt != RDR_UINT16) return rollback(RDR_ERR_UNSUPPORTED, "add_mesh: JOINTS_0 must be uint8 or uint16");
+            if (mesh.is_static) return rollback(RDR_ERR_INVALID, "add_mesh: a skinned mesh must be added with is_static = 0");
+            hp.skinned = true;
+            hp.skin_first = (uint32_t)c->h_skin_dst.size();
+            hp.rest_bb_min = hp.bb_min; hp.rest_bb_max = hp.bb_max;
+            for (size_t i = 0; i < nv; i++) {
+                float j[4], w[4];
+                if (!fetch(at[RDR_ATTR_JOINTS_0], i, 4, j) || !fetch(at[RDR_ATTR_WEIGHTS_0], i, 4, w))
+                    return rollback(RDR_ERR_INVALID, "add_mesh: JOINTS_0 / WEIGHTS_0 out of range");
+                uint32_t ji[4];
+                for (int k = 0; k < 4; k++) { ji[k] = (uint32_t)(uint16_t)j[k]; mesh.n_joints = std::max(mesh.n_joints, ji[k] + 1); }
+                c->h_skin_dst.push_back(hp.first_vertex + (uint32_t)i);
+                c->h_skin_mesh.push_back(mesh_id);
+                c->h_skin_joints.push_back(ji[0] | (ji[1] << 16));
+                c->h_skin_joints.push_back(ji[2] | (ji[3] << 16));
+                for (int k = 0; k < 4; k++) c->h_skin_weights.push_back(w[k]);
+            }
+        }
         c->prims.push_back(hp);
     }
+    mesh.joints.assign((size_t)mesh.n_joints * 16, 0.0f);
+    for (uint32_t j = 0; j < mesh.n_joints; j++) mesh.joints[j * 16] = mesh.joints[j * 16 + 5] = mesh.joints[j * 16 + 10] = mesh.joints[j * 16 + 15] = 1.0f;
     c->meshes.push_back(mesh);
     c->geometry_dirty = true;
     if (out_mesh_id) *out_mesh_id = mesh_id;
@@ -849,6 +935,49 @@ int rdr_add_mesh(rdr_ctx* c, const rdr_primitive_desc* descs, uint32_t count, co
 int rdr_set_mesh_transform(rdr_ctx* c, uint32_t mesh_id, const float model[16]) {
     if (!c || !model || mesh_id >= c->meshes.size()) return fail(c, RDR_ERR_INVALID, "set_mesh_transform: bad argument");
     memcpy(c->meshes[mesh_id].model.m, model, 64);
+    return RDR_OK;
+}
+
+int rdr_set_mesh_joints(rdr_ctx* c, uint32_t mesh_id, const float* jm, uint32_t count) {
+    if (!c || !jm || mesh_id >= c->meshes.size()) return fail(c, RDR_ERR_INVALID, "set_mesh_joints: bad argument");
+    HostMesh& mesh = c->meshes[mesh_id];
+    if (mesh.n_joints == 0) return fail(c, RDR_ERR_INVALID, "set_mesh_joints: the mesh has no skinned primitive");
+    if (count < mesh.n_joints) return fail(c, RDR_ERR_INVALID, "set_mesh_joints: fewer matrices than the largest joint index in use");
+    memcpy(mesh.joints.data(), jm, (size_t)mesh.n_joints * 64);
+    c->skin_dirty = true;
+    // culling box of each skinned primitive: around its rest box carried by every joint
+    for (uint32_t pi = mesh.first_prim; pi < mesh.first_prim + mesh.prim_count; pi++) {
+        HostPrim& p = c->prims[pi];
+        if (!p.skinned) continue;
+        vec3 lo = make3(INFINITY, INFINITY, INFINITY), hi = make3(-INFINITY, -INFINITY, -INFINITY);
+        for (uint32_t jn = 0; jn < mesh.n_joints; jn++) {
+            const float* m = jm + (size_t)jn * 16;
+            for (int k = 0; k < 8; k++) {
+                const float x = (k & 1) ? p.rest_bb_max.x : p.rest_bb_min.x, y = (k & 2) ? p.rest_bb_max.y : p.rest_bb_min.y,
+                            z = (k & 4) ? p.rest_bb_max.z : p.rest_bb_min.z;
+                const float qx = ((m[0] * x + m[4] * y) + m[8] * z) + m[12], qy = ((m[1] * x + m[5] * y) + m[9] * z) + m[13],
+                            qz = ((m[2] * x + m[6] * y) + m[10] * z) + m[14];
+                lo = make3(std::min(lo.x, qx), std::min(lo.y, qy), std::min(lo.z, qz));
+                hi = make3(std::max(hi.x, qx), std::max(hi.y, qy), std::max(hi.z, qz));
+            }
+        }
+        p.bb_min = lo; p.bb_max = hi;
+    }
+    return RDR_OK;
+}
+
+int rdr_read_primitive_positions(rdr_ctx* c, uint32_t mesh_id, uint32_t primitive, float* out, uint32_t* out_count) {
+    if (!c || mesh_id >= c->meshes.size() || primitive >= c->meshes[mesh_id].prim_count) return fail(c, RDR_ERR_INVALID, "read_primitive_positions: bad id");
+    const HostPrim& p = c->prims[c->meshes[mesh_id].first_prim + primitive];
+    if (out_count) *out_count = p.n_vertices;
+    if (!out) return RDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    RDR_TRY(upload_scene(c));
+    RDR_TRY(run_skinning(c));
+    std::vector<float> tmp((size_t)p.n_vertices * 4);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(tmp.data(), c->d_pos.as<float>() + (size_t)p.first_vertex * 4, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < p.n_vertices; i++) { out[i * 3] = tmp[i * 4]; out[i * 3 + 1] = tmp[i * 4 + 1]; out[i * 3 + 2] = tmp[i * 4 + 2]; }
     return RDR_OK;
 }
 
@@ -1013,6 +1142,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     const uint32_t W = c->W, H = c->H, S = c->settings.msaa;
     const size_t n = (size_t)W * H;
     RDR_TRY(upload_scene(c));
+    RDR_TRY(run_skinning(c));
     RDR_TRY(ensure_post_targets(c));
     HIP_TRY(c->d_depth.ensure(n * S * 4));
     HIP_TRY(c->d_vis.ensure(n * S * 4));

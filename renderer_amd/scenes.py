@@ -241,6 +241,95 @@ def upload_primitive(r, geo, material, index_type=B.UINT32):
             "bb_min": geo.pos.min(0), "bb_max": geo.pos.max(0), "material": material}
 
 
+def upload_skinned_primitive(r, geo, joints, weights, material, joint_type=B.UINT16, weight_type=B.FLOAT):
+    """Like upload_primitive plus JOINTS_0 (uint8 / uint16 x4) and WEIGHTS_0 (float, or unorm8 / unorm16 x4)."""
+    n = geo.pos.shape[0]
+    j = np.ascontiguousarray(joints, np.uint8 if joint_type == B.UINT8 else np.uint16)
+    if weight_type == B.FLOAT:
+        w = np.ascontiguousarray(weights, np.float32)
+    else:
+        top = 255 if weight_type == B.UINT8 else 65535
+        w = np.rint(np.asarray(weights, np.float64) * top).astype(np.uint8 if weight_type == B.UINT8 else np.uint16)
+    parts = [geo.pos.tobytes(), geo.nrm.tobytes(), geo.tan.tobytes(), geo.uv.tobytes(), j.tobytes(), w.tobytes(), geo.idx.tobytes()]
+    parts = [p + b"\0" * (-len(p) % 4) for p in parts]
+    offs = np.cumsum([0] + [len(p) for p in parts])
+    buf = r.load_buffer(np.frombuffer(b"".join(parts), np.uint8))
+    attrs = [B.VertexAttribute(B.ATTR_POSITION, buf, int(offs[0]), 12, B.VEC3, n, B.FLOAT, 0),
+             B.VertexAttribute(B.ATTR_NORMAL, buf, int(offs[1]), 12, B.VEC3, n, B.FLOAT, 0),
+             B.VertexAttribute(B.ATTR_TANGENT, buf, int(offs[2]), 16, B.VEC4, n, B.FLOAT, 0),
+             B.VertexAttribute(B.ATTR_TEXCOORD_0, buf, int(offs[3]), 8, B.VEC2, n, B.FLOAT, 0),
+             B.VertexAttribute(B.ATTR_JOINTS_0, buf, int(offs[4]), 0, B.VEC4, n, joint_type, 0),
+             B.VertexAttribute(B.ATTR_WEIGHTS_0, buf, int(offs[5]), 0, B.VEC4, n, weight_type, 0)]
+    return {"attributes": attrs, "indices": B.IndexBuffer(buf, B.UINT32, int(offs[6]), geo.idx.size),
+            "bb_min": geo.pos.min(0), "bb_max": geo.pos.max(0), "material": material}
+
+
+def bone_chain_weights(y, n_bones, length):
+    """Two-bone smooth weights for points at height y of a limb whose bone k starts at k * length / n_bones."""
+    seg = length / n_bones
+    f = np.clip(y / seg - 0.5, 0.0, n_bones - 1.0)
+    j0 = np.minimum(np.floor(f).astype(np.int64), n_bones - 2) if n_bones > 1 else np.zeros_like(f, np.int64)
+    u = np.clip(f - j0, 0.0, 1.0) if n_bones > 1 else np.zeros_like(f)
+    u = u * u * (3 - 2 * u)
+    joints = np.zeros((y.size, 4), np.uint16)
+    weights = np.zeros((y.size, 4), np.float32)
+    joints[:, 0], joints[:, 1] = j0, np.minimum(j0 + 1, n_bones - 1)
+    weights[:, 0], weights[:, 1] = 1.0 - u, u
+    return joints, weights
+
+
+class SkinnedFigure:
+    """Stand-in for the skinned glTF samples (CesiumMan / Fox are not on disk): a textured limb of `n_bones` bones
+    that sways under key-framed joint rotations (LINEAR slerp, one STEP and one CUBICSPLINE track), plus a second
+    primitive with 8-bit joints / weights."""
+
+    def __init__(self, r, n_bones=6, length=2.4, radius=0.22, nu=24, nv=48, tex_size=64, origin=(0.0, 0.0, 0.0), seed=61):
+        from . import animation as A
+        self.r, self.A = r, A
+        seg = length / n_bones
+        limb = cylinder(radius, length, nu, nv).transformed(translation(0, length / 2, 0))
+        bulb = uv_sphere(radius * 1.6, 16, 8).transformed(translation(0, length, 0))
+        tex = material_textures(r, tex_size, seed, tint=(1.0, 0.75, 0.55), metal_fraction=0.2)
+        prims = []
+        for geo, jt, wt in ((limb, B.UINT16, B.FLOAT), (bulb, B.UINT8, B.UINT8)):
+            joints, weights = bone_chain_weights(geo.pos[:, 1].astype(np.float64), n_bones, length)
+            prims.append(upload_skinned_primitive(r, geo, joints, weights, make_material(tex), jt, wt))
+        self.model = translation(*origin)
+        self.mesh = r.add_mesh(prims, model=self.model.T, is_static=False)
+        # bone k: child of bone k-1, offset one segment up; rest pose = straight up from the mesh origin
+        nodes = [A.Node(translation=(0, 0 if k == 0 else seg, 0), name=f"bone{k}") for k in range(n_bones)]
+        for k in range(n_bones - 1):
+            nodes[k].children.append(nodes[k + 1])
+        self.root = A.Node(matrix=self.model, children=[nodes[0]], name="figure")
+        self.root.recalculate_model()
+        inverse_bind = [np.linalg.inv(np.linalg.inv(self.model) @ n.model) for n in nodes]
+        self.skin = A.Skin(nodes, inverse_bind)
+        times = [0.0, 0.5, 1.0, 1.5, 2.0]
+        for k, n in enumerate(nodes):
+            axis = (0, 0, 1) if k % 2 == 0 else (1, 0, 0)
+            amp = 0.35 if k else 0.15
+            angles = [0.0, amp, 0.0, -amp, 0.0]
+            keys = np.stack([A.quat_from_axis_angle(axis, a * (1 + 0.1 * k)) for a in angles])
+            if k == 2:
+                n.rotation_animation = A.Animation(times, keys, A.STEP, A.REPEAT, rotation=True)
+            elif k == 3:
+                tang = np.zeros_like(keys)
+                tang[1:-1] = (keys[2:] - keys[:-2]) / 1.0
+                spline = np.stack([tang, keys, tang], 1).reshape(-1, 4)
+                n.rotation_animation = A.Animation(times, spline, A.CUBICSPLINE, A.REPEAT, rotation=True)
+            else:
+                n.rotation_animation = A.Animation(times, keys, A.LINEAR, A.MIRROR if k == 4 else A.REPEAT, rotation=True)
+        nodes[-1].scale_animation = A.Animation([0.0, 1.0, 2.0], [[1, 1, 1], [1.3, 0.8, 1.3], [1, 1, 1]], A.LINEAR, A.REPEAT)
+
+    def palette(self, t):
+        self.root.set_animation_time(t)
+        self.root.recalculate_model()
+        return self.skin.palette_for_abi(self.model)
+
+    def pose(self, t):
+        self.r.set_mesh_joints(self.mesh, self.palette(t))
+
+
 # ------------------------------------------------------------- environment
 
 

@@ -54,20 +54,26 @@ def test_config2_sponza_like_reduced(orc_capi, hip_capi):
 
 
 def test_config3_animation_batch_reduced(orc_capi, hip_capi):
-    """Config 3 (node-TRS animation, the reference's only animation form): 6 frames of a moving dynamic node; every
-    frame must match the checker, and frame order must not matter with a fixed adapted luminance."""
+    """Config 3: an animation batch with a skinned figure (key-framed joints, t_k = k / 30 s scaled up so that six
+    frames span the clip) and a node-TRS track (the reference's only animation form). Every frame must match the
+    checker, and frame order must not matter with a fixed adapted luminance."""
     ro, rh = hp.make_pair(orc_capi, hip_capi, 320, 180, **hp.small_settings(4))
     ids_o, ids_h = scenes.small_scene(ro), scenes.small_scene(rh)
-    frames = []
-    for k in range(6):
+    fig_o, fig_h = (scenes.SkinnedFigure(r, origin=(0.8, 0.0, 1.5)) for r in (ro, rh))
+
+    def set_frame(k):
         m = scenes.translation(0.3 * np.sin(k * 0.7), 0.9 + 0.1 * k, 0.4 - 0.2 * k) @ scenes.rotation_y(0.3 * k)
         ro.set_mesh_transform(ids_o["sphere"], m.T)
         rh.set_mesh_transform(ids_h["sphere"], m.T)
+        fig_o.pose(k * 11 / 30); fig_h.pose(k * 11 / 30)
+
+    frames = []
+    for k in range(6):
+        set_frame(k)
         _, out_h = compare_frame(ro, rh)
         frames.append(out_h.copy())
     # replay frame 2 after frame 5: identical bytes
-    m = scenes.translation(0.3 * np.sin(2 * 0.7), 0.9 + 0.2, 0.4 - 0.4) @ scenes.rotation_y(0.6)
-    rh.set_mesh_transform(ids_h["sphere"], m.T)
+    set_frame(2)
     again, _ = rh.render_frame(**FRAME)
     assert np.array_equal(again, frames[2])
 
