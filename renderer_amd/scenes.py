@@ -289,10 +289,12 @@ class SkinnedFigure:
         seg = length / n_bones
         limb = cylinder(radius, length, nu, nv).transformed(translation(0, length / 2, 0))
         bulb = uv_sphere(radius * 1.6, 16, 8).transformed(translation(0, length, 0))
-        tex = material_textures(r, tex_size, seed, tint=(1.0, 0.75, 0.55), metal_fraction=0.2)
-        prims = []
+        self.material_args = dict(size=tex_size, seed=seed, tint=(1.0, 0.75, 0.55), metal_fraction=0.2)
+        tex = material_textures(r, **self.material_args)
+        prims, self.parts = [], []
         for geo, jt, wt in ((limb, B.UINT16, B.FLOAT), (bulb, B.UINT8, B.UINT8)):
             joints, weights = bone_chain_weights(geo.pos[:, 1].astype(np.float64), n_bones, length)
+            self.parts.append((geo, joints, weights, jt, wt))
             prims.append(upload_skinned_primitive(r, geo, joints, weights, make_material(tex), jt, wt))
         self.model = translation(*origin)
         self.mesh = r.add_mesh(prims, model=self.model.T, is_static=False)
@@ -300,16 +302,18 @@ class SkinnedFigure:
         nodes = [A.Node(translation=(0, 0 if k == 0 else seg, 0), name=f"bone{k}") for k in range(n_bones)]
         for k in range(n_bones - 1):
             nodes[k].children.append(nodes[k + 1])
+        self.nodes = nodes
         self.root = A.Node(matrix=self.model, children=[nodes[0]], name="figure")
         self.root.recalculate_model()
-        inverse_bind = [np.linalg.inv(np.linalg.inv(self.model) @ n.model) for n in nodes]
+        # inverse bind matrices and keys are rounded to float32, the precision a glTF file stores them in
+        inverse_bind = [np.linalg.inv(np.linalg.inv(self.model) @ n.model).astype(np.float32).astype(np.float64) for n in nodes]
         self.skin = A.Skin(nodes, inverse_bind)
         times = [0.0, 0.5, 1.0, 1.5, 2.0]
         for k, n in enumerate(nodes):
             axis = (0, 0, 1) if k % 2 == 0 else (1, 0, 0)
             amp = 0.35 if k else 0.15
             angles = [0.0, amp, 0.0, -amp, 0.0]
-            keys = np.stack([A.quat_from_axis_angle(axis, a * (1 + 0.1 * k)) for a in angles])
+            keys = np.stack([A.quat_from_axis_angle(axis, a * (1 + 0.1 * k)) for a in angles]).astype(np.float32).astype(np.float64)
             if k == 2:
                 n.rotation_animation = A.Animation(times, keys, A.STEP, A.REPEAT, rotation=True)
             elif k == 3:
@@ -319,7 +323,7 @@ class SkinnedFigure:
                 n.rotation_animation = A.Animation(times, spline, A.CUBICSPLINE, A.REPEAT, rotation=True)
             else:
                 n.rotation_animation = A.Animation(times, keys, A.LINEAR, A.MIRROR if k == 4 else A.REPEAT, rotation=True)
-        nodes[-1].scale_animation = A.Animation([0.0, 1.0, 2.0], [[1, 1, 1], [1.3, 0.8, 1.3], [1, 1, 1]], A.LINEAR, A.REPEAT)
+        nodes[-1].scale_animation = A.Animation([0.0, 1.0, 2.0], np.float32([[1, 1, 1], [1.3, 0.8, 1.3], [1, 1, 1]]), A.LINEAR, A.REPEAT)
 
     def palette(self, t):
         self.root.set_animation_time(t)
