@@ -21,8 +21,10 @@
 // be compiled against any library exporting the ABI under another prefix.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -53,9 +55,12 @@ int RDR_ABI(load_image)(rdr_ctx*, const void*, size_t, uint32_t, uint32_t, int, 
 int RDR_ABI(make_texture)(rdr_ctx*, uint32_t, const rdr_sampler*, uint32_t*);
 int RDR_ABI(add_mesh)(rdr_ctx*, const rdr_primitive_desc*, uint32_t, const float*, int, uint32_t*);
 int RDR_ABI(set_mesh_transform)(rdr_ctx*, uint32_t, const float*);
+int RDR_ABI(set_mesh_joints)(rdr_ctx*, uint32_t, const float*, uint32_t);
 int RDR_ABI(set_lights)(rdr_ctx*, const rdr_point_light*, uint32_t, const rdr_directional_light*);
 int RDR_ABI(set_environment_map)(rdr_ctx*, const float* const*, uint32_t, uint32_t);
 int RDR_ABI(set_brdf_lut)(rdr_ctx*, const uint8_t*, uint32_t, uint32_t, uint32_t);
+int RDR_ABI(set_environment_equirect)(rdr_ctx*, const float*, uint32_t, uint32_t, uint32_t);
+int RDR_ABI(generate_brdf_lut)(rdr_ctx*, uint32_t, uint32_t);
 int RDR_ABI(set_camera)(rdr_ctx*, const rdr_camera*);
 int RDR_ABI(set_exposure_bias)(rdr_ctx*, float, float);
 int RDR_ABI(render_frame)(rdr_ctx*, const rdr_frame_params*, uint8_t*, int, float*);
@@ -197,6 +202,76 @@ private:
     float _near = 0.1f, _far = 100.0f, _fovOrHeight = 35.0f, _aspectRatio = 16.0f / 9.0f;
 };
 
+// ---- Animation.h ------------------------------------------------------------------
+// Same class, constructor and valueAt as the reference; the interpolation follows the glTF 2.0 specification, which
+// the reference does not (Animation.h:96 divides by t1 - t0 without subtracting t0; :91-94 returns the nearest key for
+// CUBICSPLINE). CUBICSPLINE tracks hold three values per key: in-tangent, value, out-tangent.
+enum class AnimationInterpolationCurve { eLinear, eStep, eCubicSpline };
+enum class AnimationRepeatMode { eClamp, eRepeat, eMirror };
+
+namespace anim_detail {
+inline vec3 scaled(vec3 a, float s) { return rdr::mulf(a, s); }
+inline vec3 sum(vec3 a, vec3 b) { return rdr::add(a, b); }
+inline quat scaled(quat a, float s) { return quat{a.w * s, a.x * s, a.y * s, a.z * s}; }
+inline quat sum(quat a, quat b) { return quat{a.w + b.w, a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline vec3 finish(vec3 v) { return v; }
+inline quat finish(quat q) { const float n = 1.0f / std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z); return scaled(q, n); }
+inline vec3 mix(vec3 a, vec3 b, float u) { return sum(a, scaled(rdr::sub(b, a), u)); }
+inline quat mix(quat a, quat b, float u) {  // shortest-arc slerp
+    float d = a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z;
+    if (d < 0.0f) { b = scaled(b, -1.0f); d = -d; }
+    if (d > 0.9995f) return finish(sum(a, scaled(sum(b, scaled(a, -1.0f)), u)));
+    const float th = std::acos(std::min(d, 1.0f));
+    return scaled(sum(scaled(a, std::sin((1.0f - u) * th)), scaled(b, std::sin(u * th))), 1.0f / std::sin(th));
+}
+}  // namespace anim_detail
+
+template <typename T> class Animation {
+public:
+    Animation(std::vector<float> keyframeTimes, std::vector<T> keyframeValues,
+              AnimationInterpolationCurve interpolation = AnimationInterpolationCurve::eLinear,
+              AnimationRepeatMode repeat = AnimationRepeatMode::eClamp)
+        : interpolationCurve(interpolation), repeatMode(repeat), keyframeTimes(std::move(keyframeTimes)), keyframes(std::move(keyframeValues)) {
+        const size_t want = this->keyframeTimes.size() * (interpolation == AnimationInterpolationCurve::eCubicSpline ? 3 : 1);
+        if (this->keyframeTimes.empty() || keyframes.size() != want) throw std::invalid_argument("Animation: key times and values do not match");
+    }
+    T valueAt(float t) const {
+        using namespace anim_detail;
+        const size_t n = keyframeTimes.size();
+        if (n == 1) return key(0);
+        const float first = keyframeTimes.front(), last = keyframeTimes.back(), span = last - first;
+        if (repeatMode == AnimationRepeatMode::eClamp || span <= 0.0f) t = std::min(std::max(t, first), last);
+        else {
+            const float u = (t - first) / span, loops = std::floor(u);
+            float frac = u - loops;
+            if (repeatMode == AnimationRepeatMode::eMirror && (static_cast<long long>(loops) % 2)) frac = 1.0f - frac;
+            t = first + frac * span;
+        }
+        size_t i1 = std::upper_bound(keyframeTimes.begin(), keyframeTimes.end(), t) - keyframeTimes.begin();
+        if (i1 >= n) return finish(key(n - 1));
+        if (i1 == 0) i1 = 1;
+        const size_t i0 = i1 - 1;
+        const float dt = keyframeTimes[i1] - keyframeTimes[i0];
+        const float u = std::min(std::max((t - keyframeTimes[i0]) / dt, 0.0f), 1.0f);
+        switch (interpolationCurve) {
+            case AnimationInterpolationCurve::eStep: return key(i0);
+            case AnimationInterpolationCurve::eLinear: return mix(key(i0), key(i1), u);
+            default: {
+                const float u2 = u * u, u3 = u2 * u;
+                const T v = sum(sum(scaled(keyframes[3 * i0 + 1], 2 * u3 - 3 * u2 + 1), scaled(keyframes[3 * i0 + 2], dt * (u3 - 2 * u2 + u))),
+                                sum(scaled(keyframes[3 * i1 + 1], -2 * u3 + 3 * u2), scaled(keyframes[3 * i1], dt * (u3 - u2))));
+                return finish(v);
+            }
+        }
+    }
+private:
+    T key(size_t i) const { return interpolationCurve == AnimationInterpolationCurve::eCubicSpline ? keyframes[3 * i + 1] : keyframes[i]; }
+    AnimationInterpolationCurve interpolationCurve;
+    AnimationRepeatMode repeatMode;
+    std::vector<float> keyframeTimes;
+    std::vector<T> keyframes;
+};
+
 // ---- Node.h / Node.cpp ----------------------------------------------------------
 class Node {
 public:
@@ -222,9 +297,26 @@ public:
         _model = rdr::mat_mul(parentModel, _modelLocal);
         for (auto& c : children) c->recalculateModel(_model);
     }
+    // Node.cpp:40-63
+    void setTranslationAnimation(Animation<vec3> a) { translationAnimation = std::make_unique<Animation<vec3>>(std::move(a)); setStatic(false); }
+    void setRotationAnimation(Animation<quat> a) { rotationAnimation = std::make_unique<Animation<quat>>(std::move(a)); setStatic(false); }
+    void setScaleAnimation(Animation<vec3> a) { scaleAnimation = std::make_unique<Animation<vec3>>(std::move(a)); setStatic(false); }
+    // Node.cpp:21-38
+    void setAnimationTime(float t) {
+        if (translationAnimation) setTranslation(translationAnimation->valueAt(t));
+        if (rotationAnimation) setRotation(rotationAnimation->valueAt(t));
+        if (scaleAnimation) setScale(scaleAnimation->valueAt(t));
+        for (auto& c : children) c->setAnimationTime(t);
+    }
     bool isStatic() const { return _isStatic; }
-    void setStatic(bool s) { _isStatic = s; for (auto& c : children) c->setStatic(s); }  // Node.cpp:65-75 without animation tracks
+    // Node.cpp:65-75
+    void setStatic(bool s) {
+        if (s) { if (!translationAnimation && !rotationAnimation && !scaleAnimation) _isStatic = true; }
+        else _isStatic = false;
+        for (auto& c : children) c->setStatic(_isStatic);
+    }
     const std::vector<std::shared_ptr<Node>>& childNodes() const { return children; }
+    void addChild(std::shared_ptr<Node> c) { children.push_back(std::move(c)); }
 
 private:
     std::vector<std::shared_ptr<Node>> children;
@@ -233,6 +325,26 @@ private:
     vec3 _scale{1, 1, 1};
     bool _isStatic = true, modelDirty = true, hasMatrix = false;
     mat4 _modelLocal = rdr::mat_identity(), _model = rdr::mat_identity();
+    std::unique_ptr<Animation<vec3>> translationAnimation, scaleAnimation;
+    std::unique_ptr<Animation<quat>> rotationAnimation;
+};
+
+// A glTF skin; the reference has none. jointMatrices(meshModel) is the palette rdr_set_mesh_joints takes:
+// inverse(mesh global) * joint global * inverse bind, per joint.
+class Skin {
+public:
+    std::vector<std::shared_ptr<Node>> joints;
+    std::vector<mat4> inverseBindMatrices;
+    Skin(std::vector<std::shared_ptr<Node>> j, std::vector<mat4> ibm) : joints(std::move(j)), inverseBindMatrices(std::move(ibm)) {
+        if (inverseBindMatrices.empty()) inverseBindMatrices.assign(joints.size(), rdr::mat_identity());
+        if (inverseBindMatrices.size() != joints.size()) throw std::invalid_argument("Skin: one inverse bind matrix per joint");
+    }
+    std::vector<mat4> jointMatrices(const mat4& meshModel) const {
+        const mat4 inv = rdr::mat_inverse(meshModel);
+        std::vector<mat4> out(joints.size());
+        for (size_t i = 0; i < joints.size(); i++) out[i] = rdr::mat_mul(rdr::mat_mul(inv, joints[i]->modelMatrix()), inverseBindMatrices[i]);
+        return out;
+    }
 };
 
 // ---- Mesh.h ---------------------------------------------------------------------
@@ -241,7 +353,7 @@ enum class AttributeContainerType { eScalar, eVec2, eVec3, eVec4 };
 enum class MeshPrimitiveMode { ePoints, eLines, eLineLoop, eLineStrip, eTriangles, eTriangleStrip, eTriangleFan };
 
 struct VertexAttributeDescription {
-    std::string attributeName;  // "POSITION", "NORMAL", "TANGENT", "TEXCOORD_0" (glTF semantics, main.cpp:367-400)
+    std::string attributeName;  // "POSITION", "NORMAL", "TANGENT", "TEXCOORD_0", "JOINTS_0", "WEIGHTS_0" (glTF semantics, main.cpp:367-400)
     Buffer buffer;
     size_t offset = 0;
     int32_t stride = 0;
@@ -294,7 +406,9 @@ class Mesh {
 public:
     std::vector<MeshPrimitive> primitives;
     std::shared_ptr<Node> node;
-    Mesh(std::vector<MeshPrimitive> p, std::shared_ptr<Node> n) : primitives(std::move(p)), node(std::move(n)) {}
+    std::shared_ptr<Skin> skin;  // set for meshes whose primitives carry JOINTS_0 / WEIGHTS_0
+    Mesh(std::vector<MeshPrimitive> p, std::shared_ptr<Node> n, std::shared_ptr<Skin> s = nullptr)
+        : primitives(std::move(p)), node(std::move(n)), skin(std::move(s)) {}
 };
 
 // ---- PointLight.h / DirectionalLight.h -------------------------------------------
@@ -474,6 +588,8 @@ public:
                 else if (v.attributeName == "TANGENT") name = RDR_ATTR_TANGENT;
                 else if (v.attributeName == "TEXCOORD_0") name = RDR_ATTR_TEXCOORD_0;
                 else if (v.attributeName == "BITANGENT") name = RDR_ATTR_BITANGENT;
+                else if (v.attributeName == "JOINTS_0") name = RDR_ATTR_JOINTS_0;
+                else if (v.attributeName == "WEIGHTS_0") name = RDR_ATTR_WEIGHTS_0;
                 else continue;  // attributes the shaders do not read
                 attrs[i].push_back(rdr_vertex_attribute{name, (uint32_t)v.buffer, v.offset, v.stride, (uint32_t)v.containerType, v.count,
                                                         (uint32_t)v.valueType, 0});
@@ -499,8 +615,9 @@ public:
         }
         const mat4 model = mesh.node ? mesh.node->modelMatrix() : rdr::mat_identity();
         uint32_t id = 0;
-        check(RDR_ABI(add_mesh)(ctx, descs.data(), (uint32_t)descs.size(), model.m, mesh.node ? mesh.node->isStatic() : 1, &id), "addMesh");
-        meshes.push_back(MeshSlot{id, mesh.node});
+        const int isStatic = !mesh.skin && (mesh.node ? mesh.node->isStatic() : true);
+        check(RDR_ABI(add_mesh)(ctx, descs.data(), (uint32_t)descs.size(), model.m, isStatic, &id), "addMesh");
+        meshes.push_back(MeshSlot{id, mesh.node, mesh.skin});
     }
 
     Camera& camera() { return _camera; }
@@ -518,7 +635,14 @@ public:
     // `dst` is a host pointer, or a device pointer when dstIsDevice (the frame then stays in HBM)
     void renderFrameInto(const FrameParams& fp, uint8_t* dst, bool dstIsDevice, float* avgLogLuminance = nullptr) {
         for (const MeshSlot& m : meshes)
-            if (m.node) { const mat4 model = m.node->modelMatrix(); check(RDR_ABI(set_mesh_transform)(ctx, m.id, model.m), "mesh transform"); }
+            if (m.node) {
+                const mat4 model = m.node->modelMatrix();
+                check(RDR_ABI(set_mesh_transform)(ctx, m.id, model.m), "mesh transform");
+                if (m.skin) {
+                    const std::vector<mat4> palette = m.skin->jointMatrices(model);
+                    check(RDR_ABI(set_mesh_joints)(ctx, m.id, palette[0].m, (uint32_t)palette.size()), "mesh joints");
+                }
+            }
         const rdr_camera cam = _camera.toAbi();
         check(RDR_ABI(set_camera)(ctx, &cam), "camera");
         check(RDR_ABI(set_exposure_bias)(ctx, _settings.exposureBias, _settings.gamma), "settings");
@@ -533,7 +657,7 @@ public:
     rdr_ctx* handle() { return ctx; }
 
 private:
-    struct MeshSlot { uint32_t id; std::shared_ptr<Node> node; };
+    struct MeshSlot { uint32_t id; std::shared_ptr<Node> node; std::shared_ptr<Skin> skin; };
     void check(int rc, const char* what) {
         if (rc != RDR_OK) throw std::runtime_error(std::string(what) + ": status " + std::to_string(rc) + ": " + RDR_ABI(last_error)(ctx));
     }

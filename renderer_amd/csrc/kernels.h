@@ -34,8 +34,10 @@ void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const u
                  uint32_t* keys, uint32_t* vals);
 void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles,
                    uint32_t* n_valid);
+// tiles [first_tile, end_tile) hold the views of one sample count, the first of which is view first_view
+struct RasterRange { uint32_t first_tile, end_tile, first_view; };
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, bool any_s1, bool any_s4);
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange s1, RasterRange s4);
 
 // kernels_shade.hip
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,

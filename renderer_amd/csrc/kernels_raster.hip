@@ -278,6 +278,18 @@ __global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views,
     if (local_tile >= vw.tiles_x * vw.tiles_y) return;
     const uint32_t begin = tile_start[tile], end = tile_end[tile];
     if (vw.load && begin >= end) return;  // nothing to add to what the target holds
+    if (begin >= end) {                   // nothing drawn here: the tile is just cleared
+        const int cx = (int)(local_tile % vw.tiles_x) * RDR_TILE + ((int)threadIdx.x & 15), cy = (int)(local_tile / vw.tiles_x) * RDR_TILE + ((int)threadIdx.x >> 4);
+        if (cx < (int)vw.w && cy < (int)vw.h) {
+            const size_t plane = (size_t)vw.w * vw.h, at = (size_t)cy * vw.w + cx;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                vw.depth[s * plane + at] = 1.0f;
+                if (vw.vis) vw.vis[s * plane + at] = RDR_PAIR_INVALID;
+            }
+        }
+        return;
+    }
     const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
     const int tid = (int)threadIdx.x;
     const int px = ox0 + (tid & 15), py = oy0 + (tid >> 4);
@@ -408,8 +420,11 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32
     hipLaunchKernelGGL(k_ranges, dim3((n_pairs + 255) / 256), dim3(256), 0, s, keys, n_pairs, tile_start, tile_end, n_valid);
 }
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, bool any_s1, bool any_s4) {
-    if (!n_tiles) return;
-    if (any_s1) hipLaunchKernelGGL(k_raster<1>, dim3(n_tiles), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end, 0u, 0u);
-    if (any_s4) hipLaunchKernelGGL(k_raster<4>, dim3(n_tiles), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end, 0u, 0u);
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange s1, RasterRange s4) {
+    if (s1.first_tile < s1.end_tile)
+        hipLaunchKernelGGL(k_raster<1>, dim3(s1.end_tile - s1.first_tile), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
+                           s1.first_view, s1.first_tile);
+    if (s4.first_tile < s4.end_tile)
+        hipLaunchKernelGGL(k_raster<4>, dim3(s4.end_tile - s4.first_tile), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
+                           s4.first_view, s4.first_tile);
 }

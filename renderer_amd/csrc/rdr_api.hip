@@ -452,11 +452,19 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr) {
     int cur = 0;
     RDR_TRY(bin_batch(c, b, &n_tiles, &cur));
     if (out_cur) *out_cur = cur;
-    bool s1 = false, s4 = false;
-    for (const DView& v : b.views) (v.samples == 4 ? s4 : s1) = true;
+    // tile range per sample count (views are laid out in order, so each is one interval); tiles of views this
+    // kernel does not rasterise (load == 2) are left out
+    RasterRange rr[2] = {{0xFFFFFFFFu, 0u, 0u}, {0xFFFFFFFFu, 0u, 0u}};
+    for (uint32_t vi = 0; vi < b.views.size(); vi++) {
+        const DView& v = b.views[vi];
+        if (v.load == 2u) continue;
+        RasterRange& r = rr[v.samples == 4 ? 1 : 0];
+        if (r.first_tile == 0xFFFFFFFFu) { r.first_tile = v.tile_base; r.first_view = vi; }
+        r.end_tile = v.tile_base + v.tiles_x * v.tiles_y;
+    }
     HIP_TRY(hipEventRecord(c->ev[8], c->stream));
     launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                  c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, s1, s4);
+                  c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), rr[0], rr[1]);
     HIP_TRY(hipEventRecord(c->ev[9], c->stream));
     HIP_TRY(hipGetLastError());
     return RDR_OK;

@@ -1,5 +1,6 @@
 // Host program written against the reference's scene API (include/renderer.hpp): builds a small scene the way
-// Renderer/main.cpp does (buffers -> mesh primitives on nodes -> lights -> environment), renders two frames and
+// Renderer/main.cpp does (buffers -> mesh primitives on nodes -> lights -> environment; plus a skinned flap driven by
+// key-framed joints, which the reference cannot do), renders three frames and
 // writes them, raw RGBA8, to argv[1]. tests/test_cpp_facade.py builds the same scene through the Python API and
 // compares. Compiled twice: against the CPU checker (-DRDR_ABI_PREFIX=orc_) and against the HIP library.
 #include <cmath>
@@ -31,12 +32,14 @@ static Geo grid(float s, int n, float uvScale) {
     return g;
 }
 
-static MeshPrimitive upload(Renderer& r, const Geo& g, const Material& m) {
+static MeshPrimitive upload(Renderer& r, const Geo& g, const Material& m, const std::vector<uint8_t>* joints = nullptr,
+                            const std::vector<float>* weights = nullptr) {
     std::vector<uint8_t> bin;
     auto append = [&](const void* p, size_t n) { const size_t o = bin.size(); bin.resize(o + n); std::memcpy(bin.data() + o, p, n); return o; };
     const size_t oPos = append(g.pos.data(), g.pos.size() * 4), oNrm = append(g.nrm.data(), g.nrm.size() * 4);
     const size_t oTan = append(g.tan.data(), g.tan.size() * 4), oUv = append(g.uv.data(), g.uv.size() * 4);
     const size_t oIdx = append(g.idx.data(), g.idx.size() * 2);
+    const size_t oJoints = joints ? append(joints->data(), joints->size()) : 0, oWeights = weights ? append(weights->data(), weights->size() * 4) : 0;
     const Buffer buf = r.loadBuffer(bin.data(), bin.size());
     const size_t nv = g.pos.size() / 3;
     std::vector<VertexAttributeDescription> attrs = {
@@ -46,6 +49,10 @@ static MeshPrimitive upload(Renderer& r, const Geo& g, const Material& m) {
         {"TEXCOORD_0", buf, oUv, 8, nv, AttributeContainerType::eVec2, AttributeValueType::eFloat},
         {"COLOR_0", buf, 0, 0, 0, AttributeContainerType::eVec4, AttributeValueType::eFloat},  // ignored, as by the shaders
     };
+    if (joints && weights) {
+        attrs.push_back({"JOINTS_0", buf, oJoints, 0, nv, AttributeContainerType::eVec4, AttributeValueType::eUint8});
+        attrs.push_back({"WEIGHTS_0", buf, oWeights, 0, nv, AttributeContainerType::eVec4, AttributeValueType::eFloat});
+    }
     float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
     for (size_t i = 0; i < nv; i++)
         for (int k = 0; k < 3; k++) { mn[k] = std::fmin(mn[k], g.pos[i * 3 + k]); mx[k] = std::fmax(mx[k], g.pos[i * 3 + k]); }
@@ -95,6 +102,31 @@ int main(int argc, char** argv) {
         r.addMesh(Mesh({upload(r, grid(8.0f, 4, 4.0f), mFloor)}, floorNode));
         r.addMesh(Mesh({upload(r, grid(1.2f, 2, 1.0f), mPlate)}, plateNode));
 
+        // a flap of two bones: bone 0 along the far edge (z = +0.5 of the flap), bone 1 at its middle, folding about x
+        Geo flap = grid(1.0f, 4, 1.0f);
+        std::vector<uint8_t> flapJoints;
+        std::vector<float> flapWeights;
+        for (size_t i = 0; i < flap.pos.size() / 3; i++) {
+            const float v = 0.5f - flap.pos[i * 3 + 2];
+            const float w1 = std::fmin(std::fmax(2.0f * v - 0.5f, 0.0f), 1.0f);
+            flapJoints.insert(flapJoints.end(), {0, 1, 0, 0});
+            flapWeights.insert(flapWeights.end(), {1.0f - w1, w1, 0.0f, 0.0f});
+        }
+        auto bone1 = std::make_shared<Node>(rdr::make3(0.0f, 0.0f, -0.5f), quat{1, 0, 0, 0}, rdr::make3(1, 1, 1), std::vector<std::shared_ptr<Node>>{});
+        auto bone0 = std::make_shared<Node>(rdr::make3(0.0f, 0.0f, 0.5f), quat{1, 0, 0, 0}, rdr::make3(1, 1, 1), std::vector<std::shared_ptr<Node>>{bone1});
+        auto flapNode = std::make_shared<Node>(rdr::make3(-1.5f, 0.8f, 0.5f), quat{1, 0, 0, 0}, rdr::make3(1, 1, 1), std::vector<std::shared_ptr<Node>>{bone0});
+        bone1->setRotationAnimation(Animation<quat>({0.0f, 1.0f}, {quat{1, 0, 0, 0}, quat{std::cos(0.45f), std::sin(0.45f), 0, 0}},
+                                                    AnimationInterpolationCurve::eLinear, AnimationRepeatMode::eMirror));
+        bone0->setTranslationAnimation(Animation<vec3>({0.0f, 2.0f}, {rdr::make3(0, 0, 0), rdr::make3(0, 0, 0.5f), rdr::make3(0, 1, 0),
+                                                                       rdr::make3(0, 0, 0), rdr::make3(0, 0.4f, 0.5f), rdr::make3(0, 0, 0)},
+                                                       AnimationInterpolationCurve::eCubicSpline, AnimationRepeatMode::eClamp));
+        auto skin = std::make_shared<Skin>(std::vector<std::shared_ptr<Node>>{bone0, bone1},
+                                           std::vector<mat4>{rdr::mat_translate(rdr::make3(0, 0, -0.5f)), rdr::mat_identity()});
+        Material mFlap;
+        mFlap.albedoTexture = checker;
+        mFlap.materialInfo.metallicFactor = 0.1f; mFlap.materialInfo.roughnessFactor = 0.5f;
+        r.addMesh(Mesh({upload(r, flap, mFlap, &flapJoints, &flapWeights)}, flapNode, skin));
+
         // environment: 8x8 faces, a vertical gradient; BRDF table: 16x16 ramp
         std::array<TextureInfo, 6> env;
         for (int f = 0; f < 6; f++) {
@@ -129,6 +161,12 @@ int main(int argc, char** argv) {
         root.recalculateModel(rdr::mat_identity());
         r.camera().dolly(0.5f);
         std::vector<uint8_t> f1 = r.renderFrame(fp);
+        // advance the clip: the flap folds (slerp on bone 1) while bone 0 rides a spline
+        flapNode->setAnimationTime(1.4f);
+        flapNode->recalculateModel(rdr::mat_identity());
+        std::vector<uint8_t> f2 = r.renderFrame(fp);
+        const mat4 bm = bone1->modelMatrix();
+        std::printf("bone1 model col3 = %.6f %.6f %.6f\n", bm.at(3, 0), bm.at(3, 1), bm.at(3, 2));
         const mat4 pm = plateNode->modelMatrix();
         std::printf("plate model col3 = %.6f %.6f %.6f\n", pm.at(3, 0), pm.at(3, 1), pm.at(3, 2));
         const vec3 cp = r.camera().position();
@@ -137,6 +175,7 @@ int main(int argc, char** argv) {
         if (!fo) return 3;
         std::fwrite(f0.data(), 1, f0.size(), fo);
         std::fwrite(f1.data(), 1, f1.size(), fo);
+        std::fwrite(f2.data(), 1, f2.size(), fo);
         std::fclose(fo);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from renderer_amd import _binding as B
+from renderer_amd import animation as A
 from renderer_amd import scenes
 from renderer_amd.api import Renderer, default_settings, quat_look_at
 from tests import helpers as hp
@@ -35,7 +36,7 @@ def build_orc_binary():
 def run_binary(exe, tmp_path, tag):
     out = tmp_path / f"{tag}.raw"
     p = subprocess.run([exe, str(out)], check=True, capture_output=True, text=True, timeout=120)
-    frames = np.fromfile(out, np.uint8).reshape(2, H, W, 4)
+    frames = np.fromfile(out, np.uint8).reshape(3, H, W, 4)
     return frames, p.stdout
 
 
@@ -78,6 +79,22 @@ def python_frames(capi):
     r.add_mesh([scenes.upload_primitive(r, scenes.plane(8.0, 8.0, 4, 4, uv_scale=4.0), m_floor, B.UINT16)])
     plate = r.add_mesh([scenes.upload_primitive(r, scenes.plane(1.2, 1.2, 2, 2), m_plate, B.UINT16)], model=plate_model((0.5, 0.0, 0.0)).T,
                        is_static=False)
+    # the skinned flap: two bones, joints as uint8, float weights
+    flap = scenes.plane(1.0, 1.0, 4, 4)
+    v = np.float32(0.5) - flap.pos[:, 2]
+    w1 = np.clip(np.float32(2.0) * v - np.float32(0.5), 0, 1).astype(np.float32)
+    joints = np.tile(np.uint8([0, 1, 0, 0]), (v.size, 1))
+    weights = np.stack([np.float32(1.0) - w1, w1, np.zeros_like(w1), np.zeros_like(w1)], 1)
+    bone1 = A.Node(translation=(0, 0, -0.5))
+    bone0 = A.Node(translation=(0, 0, 0.5), children=[bone1])
+    flap_node = A.Node(translation=(-1.5, 0.8, 0.5), children=[bone0])
+    bone1.rotation_animation = A.Animation([0.0, 1.0], [A.quat_from_axis_angle((1, 0, 0), 0.0), A.quat_from_axis_angle((1, 0, 0), 0.9)],
+                                           A.LINEAR, A.MIRROR, rotation=True)
+    bone0.translation_animation = A.Animation([0.0, 2.0], [[0, 0, 0], [0, 0, 0.5], [0, 1, 0], [0, 0, 0], [0, 0.4, 0.5], [0, 0, 0]], A.CUBICSPLINE, A.CLAMP)
+    flap_node.recalculate_model()
+    skin = A.Skin([bone0, bone1], [scenes.translation(0, 0, -0.5), np.eye(4)])
+    m_flap = scenes.make_material([checker, B.INVALID_ID, B.INVALID_ID, B.INVALID_ID, B.INVALID_ID], metallic=0.1, roughness=0.5)
+    flap_mesh = r.add_mesh([scenes.upload_skinned_primitive(r, flap, joints, weights, m_flap, B.UINT8, B.FLOAT)], model=flap_node.model.T, is_static=False)
     env = np.zeros((6, 8, 8, 4), np.float32)
     for f in range(6):
         for y in range(8):
@@ -105,11 +122,16 @@ def python_frames(capi):
     cam_pos = cam_pos + np.linalg.inv(rx @ ry) @ np.array([0.0, 0.0, -0.5])
     r.set_camera(position=cam_pos, euler=cam_euler)
     f1, _ = r.render_frame(exposure_mode=1, temporal_luminance=0.5)
-    return np.stack([f0, f1]), cam_pos
+    f1 = f1.copy()
+    flap_node.set_animation_time(1.4)
+    flap_node.recalculate_model()
+    r.set_mesh_joints(flap_mesh, skin.palette_for_abi(flap_node.model))
+    f2, _ = r.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    return np.stack([f0, f1, f2]), cam_pos, bone1.model[:3, 3]
 
 
 def assert_frames_close(a, b):
-    for k in range(2):
+    for k in range(3):
         d = np.abs(a[k].astype(int) - b[k].astype(int)).max(-1)
         # host matrices are built in float here and in double in the Python twin: a silhouette pixel may flip
         assert (d > 1).mean() < 2e-3, f"frame {k}: {(d > 1).sum()} pixels differ by more than 1/255"
@@ -119,7 +141,10 @@ def assert_frames_close(a, b):
 def test_facade_program_matches_python_api_on_the_checker(orc_capi, tmp_path):
     frames, stdout = run_binary(build_orc_binary(), tmp_path, "orc")
     assert "plate model col3 = -0.600000 1.250000 -0.050000" in stdout  # root T/S, arm T/R, plate T by hand
-    ref, cam_pos = python_frames(orc_capi)
+    ref, cam_pos, bone1_pos = python_frames(orc_capi)
+    bone_line = [ln for ln in stdout.splitlines() if ln.startswith("bone1")][0]
+    assert np.allclose([float(v) for v in bone_line.split("=")[1].split()], bone1_pos, atol=1e-5), "same spline and hierarchy on both sides"
+    assert not np.array_equal(frames[1], frames[2]), "the flap moved"
     cam_line = [ln for ln in stdout.splitlines() if ln.startswith("camera")][0]
     assert np.allclose([float(v) for v in cam_line.split("=")[1].split()], cam_pos, atol=1e-5)
     assert not np.array_equal(frames[0], frames[1])
@@ -133,5 +158,5 @@ def test_facade_program_on_the_hip_library(hip_capi, tmp_path):
     assert os.path.exists(exe), "tests/cpp/facade_scene_hip is built by __graft_entry__.build()"
     hip_frames, _ = run_binary(exe, tmp_path, "hip")
     orc_frames, _ = run_binary(build_orc_binary(), tmp_path, "orc")
-    for k in range(2):
+    for k in range(3):
         hp.assert_image_close(orc_frames[k], hip_frames[k])
