@@ -244,13 +244,41 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
     if (p == n_pairs - 1 && k != RDR_PAIR_INVALID) { tile_end[k] = n_pairs; n_valid[0] = n_pairs; }
 }
 
-#define RASTER_CHUNK 64
+// threads per tile and records staged per pass: single-sampled views (shadow maps), 4x multisampled view
+#ifndef RDR_RASTER_T1
+#define RDR_RASTER_T1 64
+#endif
+#ifndef RDR_RASTER_C1
+#define RDR_RASTER_C1 32
+#endif
+#ifndef RDR_RASTER_T4
+#define RDR_RASTER_T4 256
+#endif
+#ifndef RDR_RASTER_C4
+#define RDR_RASTER_C4 64
+#endif
 
-// One 256-thread block per 16x16 tile. Work is spread over (triangle, pixel)
-// items, not over triangles: for every chunk of 64 records the block sums the
-// areas of their pixel boxes inside the tile (prefix sum), and thread k takes
-// items k, k+256, ... - so sixteen 2x2-pixel triangles keep one wave busy
-// where a loop over triangles would leave 60 of its 64 lanes idle on each.
+enum { RASTER_EXACT64 = 0u, RASTER_COVER = 1u, RASTER_LOCAL32 = 2u };
+
+// A staged triangle record rewritten for one tile (same 128 bytes): 32-bit edge functions relative to the tile's
+// origin, their per-sample offsets, the record's pixel box inside the tile and what the depth test needs.
+struct RasterLocal {
+    int A[3], B[3], C[3];
+    int off[3][4];   // A sx + B sy for the four standard sample positions
+    uint32_t box;    // x0 | y0 << 4 | (width - 1) << 8 | (65536 / width + 1) << 12, tile-local
+    uint32_t id;
+    uint32_t pad;
+    double dzdX, dzdY, z00;
+    uint32_t pad2[2];
+};
+static_assert(sizeof(RasterLocal) == sizeof(DTriRec) && sizeof(DTriRec) == 128, "rewritten in place");
+
+// One block of T threads per 16x16 tile (T = 64: one wave owns the tile, barriers cost nothing and many tiles are
+// in flight per CU, which is what sparsely covered shadow-map tiles need; T = 256 for the heavier multisampled main
+// view). Work is spread over (triangle, pixel) items, not over triangles: for every chunk of 64 records the block
+// sums the areas of their pixel boxes inside the tile (prefix sum), and thread k takes items k, k+T, ... - so
+// sixteen 2x2-pixel triangles keep one wave busy where a loop over triangles would leave 60 of its 64 lanes idle
+// on each.
 //
 // Items of different triangles hit the same sample in any order, so the depth
 // test is an LDS 64-bit atomic min on (depth bits << 32 | triangle id): depths
@@ -259,13 +287,16 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 // test in list order leaves (the earlier triangle keeps a tie). The key starts
 // as (initial depth << 32 | 0): a fragment at the initial depth never beats
 // it, as LESS demands.
-template <int S>
-__global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views, uint32_t n_views, const DTriRec* __restrict__ recs,
-                                                const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
-                                                const uint32_t* __restrict__ tile_end, uint32_t first_view, uint32_t tile_origin) {
-    __shared__ uint32_t lds_rec[RASTER_CHUNK * 32];  // 64 records of 128 bytes
+template <int S, int T, int RASTER_CHUNK>
+__global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, uint32_t n_views, const DTriRec* __restrict__ recs,
+                                              const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
+                                              const uint32_t* __restrict__ tile_end, uint32_t first_view, uint32_t tile_origin) {
+    constexpr int Q = 256 / T;  // pixels of the tile per thread: pixel q*T + tid
+    static_assert(RASTER_CHUNK <= 64 && (RASTER_CHUNK & (RASTER_CHUNK - 1)) == 0 && RASTER_CHUNK <= T, "one lane of wave 0 per staged record");
+    __shared__ uint32_t lds_rec[RASTER_CHUNK * 32];  // records of 128 bytes
     __shared__ uint32_t lds_ids[RASTER_CHUNK];
     __shared__ uint32_t lds_prefix[RASTER_CHUNK + 1];
+    __shared__ uint32_t lds_cover[RASTER_CHUNK];     // RASTER_EXACT64 / RASTER_COVER / RASTER_LOCAL32, see below
     __shared__ unsigned long long lds_key[S * 256];  // [sample][pixel of the tile, row-major]
     const uint32_t tile = tile_origin + blockIdx.x;
     // view of this tile: largest v with tile_base <= tile (views are few; block-uniform loop)
@@ -278,94 +309,196 @@ __global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views,
     if (local_tile >= vw.tiles_x * vw.tiles_y) return;
     const uint32_t begin = tile_start[tile], end = tile_end[tile];
     if (vw.load && begin >= end) return;  // nothing to add to what the target holds
+    const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
+    const int tid = (int)threadIdx.x;
+    const size_t plane_px = (size_t)vw.w * vw.h;
     if (begin >= end) {                   // nothing drawn here: the tile is just cleared
-        const int cx = (int)(local_tile % vw.tiles_x) * RDR_TILE + ((int)threadIdx.x & 15), cy = (int)(local_tile / vw.tiles_x) * RDR_TILE + ((int)threadIdx.x >> 4);
-        if (cx < (int)vw.w && cy < (int)vw.h) {
-            const size_t plane = (size_t)vw.w * vw.h, at = (size_t)cy * vw.w + cx;
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                vw.depth[s * plane + at] = 1.0f;
-                if (vw.vis) vw.vis[s * plane + at] = RDR_PAIR_INVALID;
+        for (int q = 0; q < Q; q++) {
+            const int pix = q * T + tid, cx = ox0 + (pix & 15), cy = oy0 + (pix >> 4);
+            if (cx < (int)vw.w && cy < (int)vw.h) {
+                const size_t at = (size_t)cy * vw.w + cx;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    vw.depth[s * plane_px + at] = 1.0f;
+                    if (vw.vis) vw.vis[s * plane_px + at] = RDR_PAIR_INVALID;
+                }
             }
         }
         return;
     }
-    const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
-    const int tid = (int)threadIdx.x;
-    const int px = ox0 + (tid & 15), py = oy0 + (tid >> 4);
-    const bool in_view = px < (int)vw.w && py < (int)vw.h;
-    const size_t plane_px = (size_t)vw.w * vw.h;
-    const size_t o = (size_t)py * vw.w + px;
 
-    uint32_t zi[S];  // bits of the initial depth
+    uint32_t zi[Q][S];  // bits of the initial depth
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-        zi[s] = __float_as_uint((vw.load && in_view) ? vw.depth[s * plane_px + o] : 1.0f);
-        lds_key[s * 256 + tid] = (unsigned long long)zi[s] << 32;
+    for (int q = 0; q < Q; q++) {
+        const int pix = q * T + tid, px = ox0 + (pix & 15), py = oy0 + (pix >> 4);
+        const bool in_view = px < (int)vw.w && py < (int)vw.h;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            zi[q][s] = __float_as_uint((vw.load && in_view) ? vw.depth[s * plane_px + (size_t)py * vw.w + px] : 1.0f);
+            lds_key[s * 256 + pix] = (unsigned long long)zi[q][s] << 32;
+        }
     }
     const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
+    // Smallest upper depth bound of the polygons seen so far that contain the whole tile (kept by wave 0). A record
+    // whose lower depth bound over the tile is strictly greater loses the LESS test at every sample, whatever the
+    // order, so it is dropped before any per-pixel work. Bounds are taken at the tile's corners in double, rounded to
+    // float and widened by one ulp, which dwarfs the rounding of the per-sample evaluation.
+    float tile_far = 2.0f;
+    //
+    // Edge functions. E(P) = dX (Py - Yi) - dY (Px - Xi) needs 64 bits in general, but inside one tile it is
+    // E(O) + A u + B v with O the tile's origin, A = -dY, B = dX and 0 <= u, v < 4096 + 224 sub-pixels. For an
+    // unclipped triangle whose edges all have |A| + |B| <= 2^18 (1024 px) the variable part stays below 2^30, so the
+    // setup lane folds E(O) - bias into a 32-bit constant C (saturated at +-2^30, where the sign no longer depends on
+    // u, v) and rewrites the staged record in place as a RasterLocal: the per-item test is then C + A u + B v >= 0 in
+    // 32-bit multiply-adds, with the same sign as the 64-bit expression. Everything else (clipped polygons, very long
+    // edges) keeps the 64-bit path; a polygon containing the whole tile needs no test at all.
     for (uint32_t base = begin; base < end; base += RASTER_CHUNK) {
         const uint32_t cnt = min((uint32_t)RASTER_CHUNK, end - base);
         __syncthreads();  // the previous chunk's items are done with lds_rec (first pass: the keys are initialised)
         if ((uint32_t)tid < cnt) lds_ids[tid] = sorted_vals[base + tid];
         __syncthreads();
         // 32 consecutive threads copy one 128-byte record
-        for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += 256u)
+        for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += (uint32_t)T)
             lds_rec[dw] = ((const uint32_t*)(recs + lds_ids[dw >> 5]))[dw & 31u];
         __syncthreads();
-        // wave 0: area of each record's pixel box inside the tile, inclusive prefix sum over the 64 lanes
+        // wave 0: area of each record's pixel box inside the tile, inclusive prefix sum over its lanes
         if (tid < 64) {
             uint32_t area = 0;
+            bool cover = false;
+            float z_lo = 0.0f, z_hi = 2.0f;
             if ((uint32_t)tid < cnt) {
                 const DTriRec* r = (const DTriRec*)(lds_rec + tid * 32);
                 const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1);
                 const int by0 = max((int)r->py0, oy0), by1 = min((int)r->py1, oy0 + RDR_TILE - 1);
-                if (bx0 <= bx1 && by0 <= by1) area = (uint32_t)((bx1 - bx0 + 1) * (by1 - by0 + 1));
+                if (bx0 <= bx1 && by0 <= by1) {
+                    area = (uint32_t)((bx1 - bx0 + 1) * (by1 - by0 + 1));
+                    const int X0 = 256 * ox0, X1 = X0 + 256 * RDR_TILE, Y0 = 256 * oy0, Y1 = Y0 + 256 * RDR_TILE;
+                    const int n = (int)(r->n_view & 255u);
+                    cover = area == (uint32_t)(RDR_TILE * RDR_TILE);
+                    for (int i = 0; i < n && cover; i++) {  // every edge function is positive at its worst tile corner
+                        const int j = (i + 1 == n) ? 0 : i + 1;
+                        const int Xi = r->X[i], Yi = r->Y[i];
+                        const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                        const long long Emin = (long long)dX * (long long)((dX >= 0 ? Y0 : Y1) - Yi) - (long long)dY * (long long)((dY >= 0 ? X1 : X0) - Xi);
+                        if (Emin < 1) cover = false;
+                    }
+                    const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
+                    const double lo = fma(dzdX, (double)(dzdX >= 0.0 ? X0 : X1), fma(dzdY, (double)(dzdY >= 0.0 ? Y0 : Y1), z00));
+                    const double hi = fma(dzdX, (double)(dzdX >= 0.0 ? X1 : X0), fma(dzdY, (double)(dzdY >= 0.0 ? Y1 : Y0), z00));
+                    float flo = (float)lo, fhi = (float)hi;
+                    flo = flo < 0.0f ? 0.0f : (flo > 1.0f ? 1.0f : flo);
+                    fhi = fhi < 0.0f ? 0.0f : (fhi > 1.0f ? 1.0f : fhi);
+                    z_lo = flo > 0.0f ? __uint_as_float(__float_as_uint(flo) - 1u) : 0.0f;  // one ulp down / up: depths are in [0, 1]
+                    z_hi = __uint_as_float(__float_as_uint(fhi) + 1u);
+                }
             }
+            float chunk_far = cover ? z_hi : 2.0f;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) chunk_far = fminf(chunk_far, __shfl_xor(chunk_far, d));
+            tile_far = fminf(tile_far, chunk_far);
+            if (z_lo > tile_far) { area = 0; cover = false; }
+            uint32_t mode = cover ? RASTER_COVER : RASTER_EXACT64;
+            if (area && !cover) {
+                const DTriRec* r = (const DTriRec*)(lds_rec + tid * 32);
+                if ((r->n_view & 255u) == 3u) {
+                    RasterLocal f;
+                    const int Ox = 256 * ox0, Oy = 256 * oy0;
+                    bool narrow = true;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int j = i == 2 ? 0 : i + 1;
+                        const int Xi = r->X[i], Yi = r->Y[i];
+                        const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                        narrow = narrow && (abs(dX) + abs(dY) <= (1 << 18));
+                        const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+                        long long c = (long long)dX * (long long)(Oy - Yi) - (long long)dY * (long long)(Ox - Xi) - bias;
+                        if (S == 1) c += ((long long)dX - (long long)dY) * 128;  // the one sample sits at the pixel centre
+                        c = c > (1ll << 30) ? (1ll << 30) : (c < -(1ll << 30) - 1 ? -(1ll << 30) - 1 : c);
+                        f.A[i] = -dY; f.B[i] = dX; f.C[i] = (int)c;
+#pragma unroll
+                        for (int sm = 0; sm < 4; sm++) f.off[i][sm] = -dY * sxo[sm] + dX * syo[sm];
+                    }
+                    if (narrow) {
+                        const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1), by0 = max((int)r->py0, oy0);
+                        const uint32_t bw = (uint32_t)(bx1 - bx0 + 1);
+                        f.box = (uint32_t)(bx0 - ox0) | ((uint32_t)(by0 - oy0) << 4) | ((bw - 1u) << 8) | ((65536u / bw + 1u) << 12);
+                        f.id = r->id;
+                        f.pad = 0;
+                        f.dzdX = r->dzdX; f.dzdY = r->dzdY; f.z00 = r->z00;
+                        *(RasterLocal*)(lds_rec + tid * 32) = f;  // in place: this lane is the only reader of the record until the barrier
+                        mode = RASTER_LOCAL32;
+                    }
+                }
+            }
+            if ((uint32_t)tid < cnt) lds_cover[tid] = mode;
             uint32_t incl = area;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t up = __shfl_up(incl, d);
                 if (tid >= d) incl += up;
             }
-            lds_prefix[tid + 1] = incl;
+            if (tid < RASTER_CHUNK) lds_prefix[tid + 1] = incl;
             if (tid == 0) lds_prefix[0] = 0u;
         }
         __syncthreads();
         const uint32_t total = lds_prefix[RASTER_CHUNK];
-        for (uint32_t wi = (uint32_t)tid; wi < total; wi += 256u) {
+        for (uint32_t wi = (uint32_t)tid; wi < total; wi += (uint32_t)T) {
             uint32_t lo = 0, hi = cnt;  // largest lo with prefix[lo] <= wi
 #pragma unroll
-            for (int it = 0; it < 6; it++) {
+            for (int it = 0; (1 << it) < RASTER_CHUNK; it++) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (hi - lo > 1u) { if (lds_prefix[mid] <= wi) lo = mid; else hi = mid; }
             }
             const uint32_t local = wi - lds_prefix[lo];
-            const DTriRec* r = (const DTriRec*)(lds_rec + lo * 32);
-            const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1);
-            const int by0 = max((int)r->py0, oy0);
-            const uint32_t bw = (uint32_t)(bx1 - bx0 + 1);               // 1..16
-            const uint32_t row = (local * (65536u / bw + 1u)) >> 16;     // local / bw, exact for local < 256
-            const int x = bx0 + (int)(local - row * bw), y = by0 + (int)row;
-            const int n = (int)(r->n_view & 255u);
-            const int Px0 = 256 * x, Py0 = 256 * y;
+            const uint32_t mode = lds_cover[lo];
             uint32_t inside = (1u << S) - 1u;
-            for (int i = 0; i < n; i++) {
-                const int j = (i + 1 == n) ? 0 : i + 1;
-                const int Xi = r->X[i], Yi = r->Y[i];
-                const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
-                const long long E0 = (long long)dX * (long long)(Py0 - Yi) - (long long)dY * (long long)(Px0 - Xi);
-                const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+            int x, y;
+            double dzdX, dzdY, z00;
+            uint32_t rid;
+            if (mode == RASTER_LOCAL32) {
+                const RasterLocal* f = (const RasterLocal*)(lds_rec + lo * 32);
+                const uint32_t box = f->box;
+                const uint32_t bw = ((box >> 8) & 15u) + 1u;
+                const uint32_t row = (local * (box >> 12)) >> 16;        // local / bw, exact for local < 256
+                const int xl = (int)(box & 15u) + (int)(local - row * bw), yl = (int)((box >> 4) & 15u) + (int)row;
+                x = ox0 + xl; y = oy0 + yl;
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const int ax = S == 1 ? 128 : sxo[s], ay = S == 1 ? 128 : syo[s];
-                    const long long E = E0 + ((long long)dX * ay - (long long)dY * ax);
-                    if (E < bias) inside &= ~(1u << s);
+                for (int i = 0; i < 3; i++) {
+                    const int Ep = f->C[i] + f->A[i] * (xl << 8) + f->B[i] * (yl << 8);
+                    if (S == 1) { if (Ep < 0) inside = 0u; }
+                    else {
+#pragma unroll
+                        for (int sm = 0; sm < S; sm++) if (Ep + f->off[i][sm] < 0) inside &= ~(1u << sm);
+                    }
                 }
+                dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id;
+            } else {
+                const DTriRec* r = (const DTriRec*)(lds_rec + lo * 32);
+                const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1);
+                const int by0 = max((int)r->py0, oy0);
+                const uint32_t bw = (uint32_t)(bx1 - bx0 + 1);               // 1..16
+                const uint32_t row = (local * (65536u / bw + 1u)) >> 16;     // local / bw, exact for local < 256
+                x = bx0 + (int)(local - row * bw); y = by0 + (int)row;
+                const int n = (int)(r->n_view & 255u);
+                const int n_edges = mode == RASTER_COVER ? 0 : n;
+                for (int i = 0; i < n_edges; i++) {
+                    const int j = (i + 1 == n) ? 0 : i + 1;
+                    const int Xi = r->X[i], Yi = r->Y[i];
+                    const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                    const long long E0 = (long long)dX * (long long)(256 * y - Yi) - (long long)dY * (long long)(256 * x - Xi);
+                    const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        const int ax = S == 1 ? 128 : sxo[s], ay = S == 1 ? 128 : syo[s];
+                        const long long E = E0 + ((long long)dX * ay - (long long)dY * ax);
+                        if (E < bias) inside &= ~(1u << s);
+                    }
+                }
+                dzdX = r->dzdX; dzdY = r->dzdY; z00 = r->z00; rid = r->id;
             }
             if (inside) {
-                const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
-                const uint32_t rid = r->id;
+                const int Px0 = 256 * x, Py0 = 256 * y;
                 const int pix = (y - oy0) * RDR_TILE + (x - ox0);
 #pragma unroll
                 for (int s = 0; s < S; s++) {
@@ -379,22 +512,27 @@ __global__ void __launch_bounds__(256) k_raster(const DView* __restrict__ views,
         }
     }
     __syncthreads();
-    if (!in_view) return;
-    bool changed = false;
-    unsigned long long key[S];
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-        key[s] = lds_key[s * 256 + tid];
-        changed = changed || key[s] != ((unsigned long long)zi[s] << 32);
-    }
-    if (!vw.load || changed) {
+    for (int q = 0; q < Q; q++) {
+        const int pix = q * T + tid, px = ox0 + (pix & 15), py = oy0 + (pix >> 4);
+        if (!(px < (int)vw.w && py < (int)vw.h)) continue;
+        const size_t o = (size_t)py * vw.w + px;
+        bool changed = false;
+        unsigned long long key[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
-    }
-    if (vw.vis) {
+        for (int s = 0; s < S; s++) {
+            key[s] = lds_key[s * 256 + pix];
+            changed = changed || key[s] != ((unsigned long long)zi[q][s] << 32);
+        }
+        if (!vw.load || changed) {
 #pragma unroll
-        for (int s = 0; s < S; s++)
-            vw.vis[s * plane_px + o] = key[s] != ((unsigned long long)zi[s] << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
+            for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
+        }
+        if (vw.vis) {
+#pragma unroll
+            for (int s = 0; s < S; s++)
+                vw.vis[s * plane_px + o] = key[s] != ((unsigned long long)zi[q][s] << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
+        }
     }
 }
 
@@ -422,9 +560,9 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, RasterRange s1, RasterRange s4) {
     if (s1.first_tile < s1.end_tile)
-        hipLaunchKernelGGL(k_raster<1>, dim3(s1.end_tile - s1.first_tile), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
+        hipLaunchKernelGGL((k_raster<1, RDR_RASTER_T1, RDR_RASTER_C1>), dim3(s1.end_tile - s1.first_tile), dim3(RDR_RASTER_T1), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
                            s1.first_view, s1.first_tile);
     if (s4.first_tile < s4.end_tile)
-        hipLaunchKernelGGL(k_raster<4>, dim3(s4.end_tile - s4.first_tile), dim3(256), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
+        hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4>), dim3(s4.end_tile - s4.first_tile), dim3(RDR_RASTER_T4), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
                            s4.first_view, s4.first_tile);
 }
