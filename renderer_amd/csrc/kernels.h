@@ -41,7 +41,7 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DT
 
 // kernels_shade.hip
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,
-                        const DTriRec* recs, DShadeTri* out);
+                        const uint32_t* pair_offset, uint32_t n_after, const uint32_t* pair_total, DShadeTri* out);
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H);
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,

@@ -20,8 +20,14 @@
 // Bit-exactness with the CPU checker rests on three things: the fma chains
 // are written out, the edge functions are integer, and double arithmetic is
 // IEEE on both sides. This file must be compiled with -ffp-contract=off.
+#include <cstddef>
+
 #include "device_common.h"
 #include "kernels.h"
+
+#ifndef RDR_SETUP_DIAG
+#define RDR_SETUP_DIAG 0  // timing experiments only: 1 stop after the draw search, 2 after the transform, 3 before the record is written
+#endif
 
 namespace {
 
@@ -47,6 +53,88 @@ RDR_DEV uint32_t find_draw(const uint32_t* __restrict__ draw_first, uint32_t n_d
     return lo;
 }
 
+// Second half of triangle set-up, from the snapped polygon on: facing and cull, pixel box, depth plane, the
+// record. FIXED = 3 unrolls everything for an unclipped triangle; FIXED = 0 takes n at run time. Returns the number
+// of tiles the pixel box touches, 0 if the polygon is dropped.
+static_assert(offsetof(DTriRec, Y) == 36 && offsetof(DTriRec, n_view) == 72 && offsetof(DTriRec, id) == 76 && offsetof(DTriRec, px0) == 80 &&
+              offsetof(DTriRec, dzdX) == 96 && offsetof(DTriRec, z00) == 112, "finish_record writes the record as 16-byte pieces");
+
+template <int FIXED>
+RDR_DEV uint32_t finish_record(const int32_t* X, const int32_t* Y, int n_in, const ClipV (&cv)[3], const DView& vw, const DDraw& d, uint32_t tri,
+                               DTriRec& rec) {
+    const int n = FIXED ? FIXED : n_in;
+    const int W = (int)vw.w, H = (int)vw.h, S = (int)vw.samples;
+    // ---- facing: Vulkan area a = -1/2 sum(x_i y_i+1 - x_i+1 y_i), CCW front => front iff sum < 0
+    long long area2 = 0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        area2 += (long long)X[i] * Y[j] - (long long)X[j] * Y[i];
+    }
+    if (area2 == 0) return 0;
+    const bool front = area2 < 0;
+    if ((vw.cull == 2u && !front) || (vw.cull == 1u && front)) return 0;
+
+    // ---- pixel bounding box
+    int32_t minX = X[0], maxX = X[0], minY = Y[0], maxY = Y[0];
+#pragma unroll
+    for (int i = 1; i < n; i++) {
+        minX = min(minX, X[i]); maxX = max(maxX, X[i]);
+        minY = min(minY, Y[i]); maxY = max(maxY, Y[i]);
+    }
+    int ix0, ix1, iy0, iy1;
+    if (S == 1) { ix0 = (minX - 128 + 255) >> 8; ix1 = (maxX - 128) >> 8; iy0 = (minY - 128 + 255) >> 8; iy1 = (maxY - 128) >> 8; }
+    else { ix0 = minX >> 8; ix1 = maxX >> 8; iy0 = minY >> 8; iy1 = maxY >> 8; }
+    ix0 = max(ix0, 0); iy0 = max(iy0, 0);
+    ix1 = min(ix1, W - 1); iy1 = min(iy1, H - 1);
+    if (ix0 > ix1 || iy0 > iy1) return 0;
+
+    // ---- depth plane a x + b y + c w = z through the unclipped vertices
+    const double x0 = cv[0].x, y0 = cv[0].y, z0 = cv[0].z, w0 = cv[0].w;
+    const double x1 = cv[1].x, y1 = cv[1].y, z1 = cv[1].z, w1 = cv[1].w;
+    const double x2 = cv[2].x, y2 = cv[2].y, z2 = cv[2].z, w2 = cv[2].w;
+    const double m_yw = y1 * w2 - y2 * w1, m_xw = x1 * w2 - x2 * w1, m_xy = x1 * y2 - x2 * y1;
+    const double m_zw = z1 * w2 - z2 * w1, m_zy = z1 * y2 - z2 * y1, m_xz = x1 * z2 - x2 * z1;
+    const double m_yz = y1 * z2 - y2 * z1;
+    const double det = (x0 * m_yw - y0 * m_xw) + w0 * m_xy;
+    if (det == 0.0 || !isfinite(det)) return 0;
+    const double pa = ((z0 * m_yw - y0 * m_zw) + w0 * m_zy) / det;
+    const double pb = ((x0 * m_zw - z0 * m_xw) + w0 * m_xz) / det;
+    const double pc = ((x0 * m_yz - y0 * m_xz) + z0 * m_xy) / det;
+    const double sx = 2.0 / (256.0 * (double)W), sy = 2.0 / (256.0 * (double)H);
+    const double dzdX = pa * sx, dzdY = pb * sy, z00 = (pc - pa) - pb;
+    if (!isfinite(dzdX) || !isfinite(dzdY) || !isfinite(z00)) return 0;
+#if RDR_SETUP_DIAG == 3
+    if (dzdX != 12345.0) return 0;
+#endif
+
+    // ---- write the record, oriented so that the interior has positive edge functions. Neighbouring lanes write
+    // records 128 bytes apart, so every store instruction touches 64 cache lines: the record goes out as 16-byte
+    // pieces (six for a triangle) rather than field by field.
+    const uint32_t n_view = (uint32_t)n | (d.view << 8), id = d.first_tri_id + tri;
+    const uint32_t box0 = (uint32_t)(ix0 & 0xFFFF) | ((uint32_t)iy0 << 16), box1 = (uint32_t)(ix1 & 0xFFFF) | ((uint32_t)iy1 << 16);
+    uint4* q = (uint4*)&rec;
+    if (FIXED == 3) {
+        const bool flip = area2 < 0;
+        const int32_t xa = flip ? X[2] : X[0], xc = flip ? X[0] : X[2], ya = flip ? Y[2] : Y[0], yc = flip ? Y[0] : Y[2];
+        q[0] = make_uint4((uint32_t)xa, (uint32_t)X[1], (uint32_t)xc, 0u);             // X[0..3]
+        q[1] = make_uint4(0u, 0u, 0u, 0u);                                             // (the whole 128-byte line is written: no partial-line write-back)
+        q[2] = make_uint4(0u, (uint32_t)ya, (uint32_t)Y[1], (uint32_t)yc);             // X[8], Y[0..2]
+        q[3] = make_uint4(0u, 0u, 0u, 0u);
+        q[4] = make_uint4(0u, 0u, n_view, id);                                         // Y[7], Y[8], n_view, id
+    } else {
+        if (area2 < 0) { for (int i = 0; i < n; i++) { rec.X[i] = X[n - 1 - i]; rec.Y[i] = Y[n - 1 - i]; } }
+        else { for (int i = 0; i < n; i++) { rec.X[i] = X[i]; rec.Y[i] = Y[i]; } }
+        rec.n_view = n_view; rec.id = id;
+    }
+    q[5] = make_uint4(box0, box1, 0u, 0u);                                             // px0 py0 | px1 py1 | pad | alignment
+    const unsigned long long ux = (unsigned long long)__double_as_longlong(dzdX), uy = (unsigned long long)__double_as_longlong(dzdY),
+                             uz = (unsigned long long)__double_as_longlong(z00);
+    q[6] = make_uint4((uint32_t)ux, (uint32_t)(ux >> 32), (uint32_t)uy, (uint32_t)(uy >> 32));
+    q[7] = make_uint4((uint32_t)uz, (uint32_t)(uz >> 32), 0u, 0u);
+    return (uint32_t)((ix1 / RDR_TILE - ix0 / RDR_TILE + 1) * (iy1 / RDR_TILE - iy0 / RDR_TILE + 1));
+}
+
 __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, const DDraw* __restrict__ draws,
                                                const uint32_t* __restrict__ draw_first, uint32_t n_draws, uint32_t n_inst,
                                                const DPrim* __restrict__ prims, const float4* __restrict__ pos,
@@ -55,13 +143,15 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
     const uint32_t inst = blockIdx.x * 256u + threadIdx.x;
     if (inst >= n_inst) return;
     const uint32_t di = find_draw(draw_first, n_draws, inst);
+#if RDR_SETUP_DIAG == 1
+    pair_count[inst] = di == 0xFFFFFFFFu ? 1u : 0u; return;
+#endif
     const DDraw& d = draws[di];
     const DView& vw = views[d.view];
     const DPrim& pr = prims[d.prim];
     const uint32_t tri = inst - d.first_instance;
     DTriRec& rec = recs[inst];
-    uint32_t count = 0;
-    rec.n_view = 0;
+    uint32_t count = 0;  // records of dropped triangles are never read (they own no pair) and are left unwritten
     do {
         const uint32_t* ip = idx + pr.first_index + 3u * tri;
         const float4 p0 = pos[pr.first_vertex + ip[0]], p1 = pos[pr.first_vertex + ip[1]], p2 = pos[pr.first_vertex + ip[2]];
@@ -74,7 +164,10 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
 #pragma unroll
         for (int i = 0; i < 3; i++) finite = finite && isfinite(cv[i].x) && isfinite(cv[i].y) && isfinite(cv[i].z) && isfinite(cv[i].w);
         if (!finite) break;
-        const int W = (int)vw.w, H = (int)vw.h, S = (int)vw.samples;
+#if RDR_SETUP_DIAG == 2
+        if (cv[0].x != 12345.0f) break;
+#endif
+        const int W = (int)vw.w, H = (int)vw.h;
         const float kx = 32768.0f / (float)W, ky = 32768.0f / (float)H;
         const float halfW256 = 128.0f * (float)W, halfH256 = 128.0f * (float)H;
 
@@ -90,10 +183,11 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
             if (outside) need |= 1u << plane;
         }
         if (rejected) break;
-        int32_t X[RDR_MAX_POLY], Y[RDR_MAX_POLY];
-        int n = 3;
-        bool ok = true;
+        // The unclipped case (nearly every triangle) is kept apart so that its three vertices stay in registers; the
+        // polygon arrays of the clipped case live in scratch memory.
         if (need == 0) {
+            int32_t X[3], Y[3];
+            bool ok = true;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const float xn = cv[i].x / cv[i].w, yn = cv[i].y / cv[i].w;
@@ -101,7 +195,12 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
                 if (!(fabsf(fx) <= 16777216.0f) || !(fabsf(fy) <= 16777216.0f)) ok = false;
                 X[i] = (int32_t)fx; Y[i] = (int32_t)fy;
             }
+            if (!ok) break;
+            count = finish_record<3>(X, Y, 3, cv, vw, d, tri, rec);
         } else {
+            int32_t X[RDR_MAX_POLY], Y[RDR_MAX_POLY];
+            int n = 3;
+            bool ok = true;
             ClipV poly[12], tmp[12];
             poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2];
             for (int plane = 0; plane < 6 && ok; plane++) {
@@ -139,59 +238,17 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
                     X[i] = (int32_t)fx; Y[i] = (int32_t)fy;
                 }
             }
+            if (!ok) break;
+            count = finish_record<0>(X, Y, n, cv, vw, d, tri, rec);
         }
-        if (!ok) break;
-
-        // ---- facing: Vulkan area a = -1/2 sum(x_i y_i+1 - x_i+1 y_i), CCW front => front iff sum < 0
-        long long area2 = 0;
-        for (int i = 0; i < n; i++) {
-            const int j = (i + 1 == n) ? 0 : i + 1;
-            area2 += (long long)X[i] * Y[j] - (long long)X[j] * Y[i];
-        }
-        if (area2 == 0) break;
-        const bool front = area2 < 0;
-        if ((vw.cull == 2u && !front) || (vw.cull == 1u && front)) break;
-
-        // ---- pixel bounding box
-        int32_t minX = X[0], maxX = X[0], minY = Y[0], maxY = Y[0];
-        for (int i = 1; i < n; i++) {
-            minX = min(minX, X[i]); maxX = max(maxX, X[i]);
-            minY = min(minY, Y[i]); maxY = max(maxY, Y[i]);
-        }
-        int ix0, ix1, iy0, iy1;
-        if (S == 1) { ix0 = (minX - 128 + 255) >> 8; ix1 = (maxX - 128) >> 8; iy0 = (minY - 128 + 255) >> 8; iy1 = (maxY - 128) >> 8; }
-        else { ix0 = minX >> 8; ix1 = maxX >> 8; iy0 = minY >> 8; iy1 = maxY >> 8; }
-        ix0 = max(ix0, 0); iy0 = max(iy0, 0);
-        ix1 = min(ix1, W - 1); iy1 = min(iy1, H - 1);
-        if (ix0 > ix1 || iy0 > iy1) break;
-
-        // ---- depth plane a x + b y + c w = z through the unclipped vertices
-        const double x0 = cv[0].x, y0 = cv[0].y, z0 = cv[0].z, w0 = cv[0].w;
-        const double x1 = cv[1].x, y1 = cv[1].y, z1 = cv[1].z, w1 = cv[1].w;
-        const double x2 = cv[2].x, y2 = cv[2].y, z2 = cv[2].z, w2 = cv[2].w;
-        const double m_yw = y1 * w2 - y2 * w1, m_xw = x1 * w2 - x2 * w1, m_xy = x1 * y2 - x2 * y1;
-        const double m_zw = z1 * w2 - z2 * w1, m_zy = z1 * y2 - z2 * y1, m_xz = x1 * z2 - x2 * z1;
-        const double m_yz = y1 * z2 - y2 * z1;
-        const double det = (x0 * m_yw - y0 * m_xw) + w0 * m_xy;
-        if (det == 0.0 || !isfinite(det)) break;
-        const double pa = ((z0 * m_yw - y0 * m_zw) + w0 * m_zy) / det;
-        const double pb = ((x0 * m_zw - z0 * m_xw) + w0 * m_xz) / det;
-        const double pc = ((x0 * m_yz - y0 * m_xz) + z0 * m_xy) / det;
-        const double sx = 2.0 / (256.0 * (double)W), sy = 2.0 / (256.0 * (double)H);
-        const double dzdX = pa * sx, dzdY = pb * sy, z00 = (pc - pa) - pb;
-        if (!isfinite(dzdX) || !isfinite(dzdY) || !isfinite(z00)) break;
-
-        // ---- write the record, oriented so that the interior has positive edge functions
-        if (area2 < 0) { for (int i = 0; i < n; i++) { rec.X[i] = X[n - 1 - i]; rec.Y[i] = Y[n - 1 - i]; } }
-        else { for (int i = 0; i < n; i++) { rec.X[i] = X[i]; rec.Y[i] = Y[i]; } }
-        rec.id = d.first_tri_id + tri;
-        rec.px0 = (int16_t)ix0; rec.py0 = (int16_t)iy0; rec.px1 = (int16_t)ix1; rec.py1 = (int16_t)iy1;
-        rec.dzdX = dzdX; rec.dzdY = dzdY; rec.z00 = z00;
-        rec.n_view = (uint32_t)n | (d.view << 8);
-        count = (uint32_t)((ix1 / RDR_TILE - ix0 / RDR_TILE + 1) * (iy1 / RDR_TILE - iy0 / RDR_TILE + 1));
     } while (false);
     pair_count[inst] = count;
-    if (count) atomicAdd(n_binned, 1u);
+    // One atomic per wave, spread over RDR_BINNED_SLOTS counters a cache line apart (the host adds them up): atomics
+    // on one address are served one after the other, and a kernel is not over until its last one has landed, which
+    // for one shared counter took three times longer than all the set-up work.
+    const unsigned long long alive = __ballot(count != 0u);
+    if (alive && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u)
+        atomicAdd(n_binned + (((blockIdx.x << 2) | (threadIdx.x >> 6)) & (RDR_BINNED_SLOTS - 1u)) * 32u, (uint32_t)__popcll(alive));
 }
 
 // One thread per candidate pair. pair_offset is the exclusive scan of pair_count.

@@ -362,14 +362,16 @@ RDR_DEV uint32_t find_draw_by_tri(const uint32_t* __restrict__ first_tri, uint32
 }
 
 // One thread per triangle of a view's draw list (index = visibility id): vertex stage, stored for the fragments.
-// `recs` are the rasteriser's records of the same triangles; a triangle that set-up dropped (clipped away,
-// culled, degenerate) can never be visible and is skipped.
+// `pair_offset` is the rasteriser's exclusive scan of (triangle, tile) pair counts, starting at this view's first
+// triangle and running on for `n_after` instances, with the grand total in *pair_total: a triangle that owns no
+// pair (clipped away, culled, degenerate) can never be visible and is skipped.
 __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ frp, const DDraw* __restrict__ draws,
                                                      const uint32_t* __restrict__ first_tri, uint32_t n_draws, uint32_t n_tris,
-                                                     const DTriRec* __restrict__ recs, DShadeTri* __restrict__ out) {
+                                                     const uint32_t* __restrict__ pair_offset, uint32_t n_after,
+                                                     const uint32_t* __restrict__ pair_total, DShadeTri* __restrict__ out) {
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
     if (id >= n_tris) return;
-    if ((recs[id].n_view & 255u) == 0u) return;
+    if ((id + 1u < n_after ? pair_offset[id + 1u] : pair_total[0]) == pair_offset[id]) return;
     const uint32_t di = find_draw_by_tri(first_tri, n_draws, id);
     DShadeTri t;
     shade_tri_setup(*frp, draws[di], id - first_tri[di], t);
@@ -647,9 +649,10 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
 }  // namespace
 
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,
-                        const DTriRec* recs, DShadeTri* out) {
+                        const uint32_t* pair_offset, uint32_t n_after, const uint32_t* pair_total, DShadeTri* out) {
     if (!n_tris) return;
-    hipLaunchKernelGGL(k_shade_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, fr, draws, first_tri, n_draws, n_tris, recs, out);
+    hipLaunchKernelGGL(k_shade_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, fr, draws, first_tri, n_draws, n_tris, pair_offset, n_after,
+                       pair_total, out);
 }
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H) {

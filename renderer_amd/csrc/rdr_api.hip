@@ -135,11 +135,12 @@ struct rdr_ctx {
     bool have_frame = false, have_post = false;
 
     // raster scratch
-    DevBuf d_views, d_draws, d_draw_first, d_first_tri, d_recs, d_pair_count, d_scan, d_hist, d_tile_start, d_tile_end, d_counters, d_frame;
+    DevBuf d_views, d_draws, d_draw_first, d_first_tri, d_recs, d_pair_count, d_scan, d_hist, d_tile_start, d_tile_end, d_counters, d_binned, d_frame;
     DevBuf d_keys[2], d_vals[2];
     DevBuf d_shade_tris;  // DShadeTri per triangle of the view being shaded
     PinBuf h_stage, h_read;
     std::vector<DDraw> main_draws;  // opaque draws of the last frame (kept for read-backs)
+    uint32_t batch_instances = 0;   // triangle instances of the last raster batch
 
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     rdr_frame_stats stats{};
@@ -393,6 +394,7 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
     }
     if (inst64 >= 0xFFFFFFF0ull) return fail(c, RDR_ERR_CAPACITY, "more than 2^32 triangle instances in one batch");
     const uint32_t n_inst = (uint32_t)inst64;
+    c->batch_instances = n_inst;
     draw_first[n_draws] = n_inst;
     // stage the tables in pinned memory and upload
     const size_t sz_views = b.views.size() * sizeof(DView), sz_draws = std::max<size_t>(n_draws, 1) * sizeof(DDraw), sz_first = (n_draws + 1) * 4;
@@ -415,12 +417,12 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
     HIP_TRY(c->d_tile_start.ensure(std::max<size_t>(n_tiles, 1) * 4));
     HIP_TRY(c->d_tile_end.ensure(std::max<size_t>(n_tiles, 1) * 4));
     HIP_TRY(c->d_scan.ensure((scan_scratch_words(n_inst) + 16) * 4));
-    uint32_t* counters = c->d_counters.as<uint32_t>();  // [0] pair total, [1] triangles binned (frame), [2] scratch total, [3] valid pairs
+    uint32_t* counters = c->d_counters.as<uint32_t>();  // [0] pair total, [2] scratch total, [3] valid pairs
     launch_setup(c->stream, c->d_views.as<DView>(), c->d_draws.as<DDraw>(), c->d_draw_first.as<uint32_t>(), n_draws, n_inst,
                  c->d_prims.as<DPrim>(), c->d_pos.p, c->d_idx.as<uint32_t>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(),
-                 counters + 1);
+                 c->d_binned.as<uint32_t>());
     launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
-    HIP_TRY(c->h_read.ensure(64));
+    HIP_TRY(c->h_read.ensure(64 + RDR_BINNED_SLOTS * 128));
     HIP_TRY(hipMemcpyAsync(c->h_read.p, counters, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t n_pairs = c->h_read.as<uint32_t>()[0];
@@ -727,7 +729,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_views, &c->d_draws,
                       &c->d_draw_first, &c->d_first_tri, &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start, &c->d_tile_end,
-                      &c->d_counters, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_counters, &c->d_binned, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
@@ -1156,6 +1158,8 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     HIP_TRY(c->d_vis.ensure(n * S * 4));
     c->stats = rdr_frame_stats{};
     HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64, c->stream));
+    HIP_TRY(c->d_binned.ensure(RDR_BINNED_SLOTS * 128));
+    HIP_TRY(hipMemsetAsync(c->d_binned.p, 0, RDR_BINNED_SLOTS * 128, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const vec3 cam_pos = c->camera.position;
     const mat4 viewproj = c->camera.view_proj();
@@ -1249,11 +1253,13 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     DShadeTri* tris_main = c->d_shade_tris.as<DShadeTri>();
     DShadeTri* tris_blend = tris_main + n_main_tris;
     launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_main_draw, c->d_first_tri.as<uint32_t>() + first_main_draw,
-                       (uint32_t)n_main_draws, n_main_tris, c->d_recs.as<DTriRec>() + main_first_instance, tris_main);
+                       (uint32_t)n_main_draws, n_main_tris, c->d_pair_count.as<uint32_t>() + main_first_instance,
+                       c->batch_instances - main_first_instance, c->d_counters.as<uint32_t>(), tris_main);
     if (have_blend)
         launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_blend_draw,
                            c->d_first_tri.as<uint32_t>() + first_blend_draw, (uint32_t)n_blend_draws, n_blend_tris,
-                           c->d_recs.as<DTriRec>() + blend_first_instance, tris_blend);
+                           c->d_pair_count.as<uint32_t>() + blend_first_instance, c->batch_instances - blend_first_instance,
+                           c->d_counters.as<uint32_t>(), tris_blend);
     HIP_TRY(hipEventRecord(c->ev[6], c->stream));
     launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
                         (S == 4 && have_blend) ? c->d_samples.p : nullptr, c->d_tile_start.as<uint32_t>() + blend_tile_base,
@@ -1277,9 +1283,9 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     HIP_TRY(hipGetLastError());
     c->have_frame = true;
     c->stats.exposure = exposure;
-    HIP_TRY(c->h_read.ensure(64));
+    HIP_TRY(c->h_read.ensure(64 + RDR_BINNED_SLOTS * 128));
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 16, c->d_lum.as<float>() + 256, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 32, c->d_counters.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 64, c->d_binned.p, RDR_BINNED_SLOTS * 128, hipMemcpyDeviceToHost, c->stream));
     if (out_rgba8) HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     // With a device destination the call only enqueues; rdr_synchronize() (or the next frame's first
@@ -1296,7 +1302,8 @@ int rdr_synchronize(rdr_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->have_frame && c->h_read.p) {
         memcpy(&c->last_avg_log_lum, c->h_read.as<uint8_t>() + 16, 4);
-        uint32_t binned; memcpy(&binned, c->h_read.as<uint8_t>() + 32, 4);
+        uint32_t binned = 0;
+        for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) binned += c->h_read.as<uint32_t>()[16 + k * 32];
         c->stats.triangles_binned = binned;
         c->stats.avg_log_luminance = c->last_avg_log_lum;
         float ms = 0.0f;

@@ -8,6 +8,7 @@
 #define RDR_MAX_CASCADES 4
 #define RDR_MAX_TEX_LEVELS 16
 #define RDR_PAIR_INVALID 0xFFFFFFFFu
+#define RDR_BINNED_SLOTS 64u     // counters (128 bytes apart) the binned-triangle statistic is spread over
 
 // Material block of one primitive (PBRInfo + AlphaInfo of the reference,
 // read by pbr.frag:21-37) plus its five texture slots.
