@@ -44,9 +44,12 @@ void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, con
                         const uint32_t* pair_offset, uint32_t n_after, const uint32_t* pair_total, DShadeTri* out);
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H);
+// blended pass: fragment list slots are handed out in runs of RDR_FRAG_RUN; `capacity` slots exist (see blend_capacity)
+#define RDR_FRAG_RUN 128u
+#define RDR_BLEND_SHADE_BLOCKS 2048u
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
-                         void* hdr);
+                         void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity);
 
 // kernels_ibl.hip
 // per-frame skinning of the vertex arena (kernels_skin.hip): rest pose + joints/weights + palette -> pos/attr

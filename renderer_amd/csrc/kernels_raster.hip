@@ -24,10 +24,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
-
-#ifndef RDR_SETUP_DIAG
-#define RDR_SETUP_DIAG 0  // timing experiments only: 1 stop after the draw search, 2 after the transform, 3 before the record is written
-#endif
+#include "raster_common.h"
 
 namespace {
 
@@ -61,7 +58,7 @@ static_assert(offsetof(DTriRec, Y) == 36 && offsetof(DTriRec, n_view) == 72 && o
 
 template <int FIXED>
 RDR_DEV uint32_t finish_record(const int32_t* X, const int32_t* Y, int n_in, const ClipV (&cv)[3], const DView& vw, const DDraw& d, uint32_t tri,
-                               DTriRec& rec) {
+                               DTriRec& rec, uint32_t& box_area) {
     const int n = FIXED ? FIXED : n_in;
     const int W = (int)vw.w, H = (int)vw.h, S = (int)vw.samples;
     // ---- facing: Vulkan area a = -1/2 sum(x_i y_i+1 - x_i+1 y_i), CCW front => front iff sum < 0
@@ -104,9 +101,6 @@ RDR_DEV uint32_t finish_record(const int32_t* X, const int32_t* Y, int n_in, con
     const double sx = 2.0 / (256.0 * (double)W), sy = 2.0 / (256.0 * (double)H);
     const double dzdX = pa * sx, dzdY = pb * sy, z00 = (pc - pa) - pb;
     if (!isfinite(dzdX) || !isfinite(dzdY) || !isfinite(z00)) return 0;
-#if RDR_SETUP_DIAG == 3
-    if (dzdX != 12345.0) return 0;
-#endif
 
     // ---- write the record, oriented so that the interior has positive edge functions. Neighbouring lanes write
     // records 128 bytes apart, so every store instruction touches 64 cache lines: the record goes out as 16-byte
@@ -132,6 +126,7 @@ RDR_DEV uint32_t finish_record(const int32_t* X, const int32_t* Y, int n_in, con
                              uz = (unsigned long long)__double_as_longlong(z00);
     q[6] = make_uint4((uint32_t)ux, (uint32_t)(ux >> 32), (uint32_t)uy, (uint32_t)(uy >> 32));
     q[7] = make_uint4((uint32_t)uz, (uint32_t)(uz >> 32), 0u, 0u);
+    box_area = (uint32_t)(ix1 - ix0 + 1) * (uint32_t)(iy1 - iy0 + 1);
     return (uint32_t)((ix1 / RDR_TILE - ix0 / RDR_TILE + 1) * (iy1 / RDR_TILE - iy0 / RDR_TILE + 1));
 }
 
@@ -141,18 +136,19 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
                                                const uint32_t* __restrict__ idx, DTriRec* __restrict__ recs,
                                                uint32_t* __restrict__ pair_count, uint32_t* __restrict__ n_binned) {
     const uint32_t inst = blockIdx.x * 256u + threadIdx.x;
-    if (inst >= n_inst) return;
-    const uint32_t di = find_draw(draw_first, n_draws, inst);
-#if RDR_SETUP_DIAG == 1
-    pair_count[inst] = di == 0xFFFFFFFFu ? 1u : 0u; return;
-#endif
-    const DDraw& d = draws[di];
-    const DView& vw = views[d.view];
-    const DPrim& pr = prims[d.prim];
-    const uint32_t tri = inst - d.first_instance;
-    DTriRec& rec = recs[inst];
+    const bool valid = inst < n_inst;  // lanes past the end stay for the wave-wide sums at the bottom
     uint32_t count = 0;  // records of dropped triangles are never read (they own no pair) and are left unwritten
+    uint32_t box_area = 0;
+    bool blended_view = false;
     do {
+        if (!valid) break;
+        const uint32_t di = find_draw(draw_first, n_draws, inst);
+        const DDraw& d = draws[di];
+        const DView& vw = views[d.view];
+        const DPrim& pr = prims[d.prim];
+        const uint32_t tri = inst - d.first_instance;
+        DTriRec& rec = recs[inst];
+        blended_view = vw.load == 2u;
         const uint32_t* ip = idx + pr.first_index + 3u * tri;
         const float4 p0 = pos[pr.first_vertex + ip[0]], p1 = pos[pr.first_vertex + ip[1]], p2 = pos[pr.first_vertex + ip[2]];
         ClipV cv[3];
@@ -164,9 +160,6 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
 #pragma unroll
         for (int i = 0; i < 3; i++) finite = finite && isfinite(cv[i].x) && isfinite(cv[i].y) && isfinite(cv[i].z) && isfinite(cv[i].w);
         if (!finite) break;
-#if RDR_SETUP_DIAG == 2
-        if (cv[0].x != 12345.0f) break;
-#endif
         const int W = (int)vw.w, H = (int)vw.h;
         const float kx = 32768.0f / (float)W, ky = 32768.0f / (float)H;
         const float halfW256 = 128.0f * (float)W, halfH256 = 128.0f * (float)H;
@@ -196,7 +189,7 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
                 X[i] = (int32_t)fx; Y[i] = (int32_t)fy;
             }
             if (!ok) break;
-            count = finish_record<3>(X, Y, 3, cv, vw, d, tri, rec);
+            count = finish_record<3>(X, Y, 3, cv, vw, d, tri, rec, box_area);
         } else {
             int32_t X[RDR_MAX_POLY], Y[RDR_MAX_POLY];
             int n = 3;
@@ -239,16 +232,30 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
                 }
             }
             if (!ok) break;
-            count = finish_record<0>(X, Y, n, cv, vw, d, tri, rec);
+            count = finish_record<0>(X, Y, n, cv, vw, d, tri, rec, box_area);
         }
     } while (false);
-    pair_count[inst] = count;
+    if (valid) pair_count[inst] = count;
     // One atomic per wave, spread over RDR_BINNED_SLOTS counters a cache line apart (the host adds them up): atomics
     // on one address are served one after the other, and a kernel is not over until its last one has landed, which
     // for one shared counter took three times longer than all the set-up work.
     const unsigned long long alive = __ballot(count != 0u);
-    if (alive && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)__ballot(1)) - 1u)
-        atomicAdd(n_binned + (((blockIdx.x << 2) | (threadIdx.x >> 6)) & (RDR_BINNED_SLOTS - 1u)) * 32u, (uint32_t)__popcll(alive));
+    uint32_t* slot = n_binned + (((blockIdx.x << 2) | (threadIdx.x >> 6)) & (RDR_BINNED_SLOTS - 1u)) * 32u;
+    const bool leader = (threadIdx.x & 63u) == 0u;
+    if (alive && leader) atomicAdd(slot, (uint32_t)__popcll(alive));
+    // Triangles of the blended view (load == 2): their (triangle, tile) pairs and the pixels of their boxes bound
+    // the fragment list of the blended pass from above; the host sizes that list from these sums.
+    const bool blended = count != 0u && blended_view;
+    if (__ballot(blended)) {
+        unsigned long long area = blended ? (unsigned long long)box_area : 0ull;
+        uint32_t pairs = blended ? count : 0u;
+#pragma unroll
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            area += ((unsigned long long)(uint32_t)__shfl_xor((int)(area >> 32), dlt) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)area, dlt);
+            pairs += (uint32_t)__shfl_xor((int)pairs, dlt);
+        }
+        if (leader) { atomicAdd(slot + 1, pairs); atomicAdd((unsigned long long*)(slot + 2), area); }
+    }
 }
 
 // One thread per candidate pair. pair_offset is the exclusive scan of pair_count.
@@ -314,21 +321,6 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 #ifndef RDR_RASTER_C4
 #define RDR_RASTER_C4 64
 #endif
-
-enum { RASTER_EXACT64 = 0u, RASTER_COVER = 1u, RASTER_LOCAL32 = 2u };
-
-// A staged triangle record rewritten for one tile (same 128 bytes): 32-bit edge functions relative to the tile's
-// origin, their per-sample offsets, the record's pixel box inside the tile and what the depth test needs.
-struct RasterLocal {
-    int A[3], B[3], C[3];
-    int off[3][4];   // A sx + B sy for the four standard sample positions
-    uint32_t box;    // x0 | y0 << 4 | (width - 1) << 8 | (65536 / width + 1) << 12, tile-local
-    uint32_t id;
-    uint32_t pad;
-    double dzdX, dzdY, z00;
-    uint32_t pad2[2];
-};
-static_assert(sizeof(RasterLocal) == sizeof(DTriRec) && sizeof(DTriRec) == 128, "rewritten in place");
 
 // One block of T threads per 16x16 tile (T = 64: one wave owns the tile, barriers cost nothing and many tiles are
 // in flight per CU, which is what sparsely covered shadow-map tiles need; T = 256 for the heavier multisampled main
@@ -456,38 +448,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
             tile_far = fminf(tile_far, chunk_far);
             if (z_lo > tile_far) { area = 0; cover = false; }
             uint32_t mode = cover ? RASTER_COVER : RASTER_EXACT64;
-            if (area && !cover) {
-                const DTriRec* r = (const DTriRec*)(lds_rec + tid * 32);
-                if ((r->n_view & 255u) == 3u) {
-                    RasterLocal f;
-                    const int Ox = 256 * ox0, Oy = 256 * oy0;
-                    bool narrow = true;
-#pragma unroll
-                    for (int i = 0; i < 3; i++) {
-                        const int j = i == 2 ? 0 : i + 1;
-                        const int Xi = r->X[i], Yi = r->Y[i];
-                        const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
-                        narrow = narrow && (abs(dX) + abs(dY) <= (1 << 18));
-                        const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
-                        long long c = (long long)dX * (long long)(Oy - Yi) - (long long)dY * (long long)(Ox - Xi) - bias;
-                        if (S == 1) c += ((long long)dX - (long long)dY) * 128;  // the one sample sits at the pixel centre
-                        c = c > (1ll << 30) ? (1ll << 30) : (c < -(1ll << 30) - 1 ? -(1ll << 30) - 1 : c);
-                        f.A[i] = -dY; f.B[i] = dX; f.C[i] = (int)c;
-#pragma unroll
-                        for (int sm = 0; sm < 4; sm++) f.off[i][sm] = -dY * sxo[sm] + dX * syo[sm];
-                    }
-                    if (narrow) {
-                        const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1), by0 = max((int)r->py0, oy0);
-                        const uint32_t bw = (uint32_t)(bx1 - bx0 + 1);
-                        f.box = (uint32_t)(bx0 - ox0) | ((uint32_t)(by0 - oy0) << 4) | ((bw - 1u) << 8) | ((65536u / bw + 1u) << 12);
-                        f.id = r->id;
-                        f.pad = 0;
-                        f.dzdX = r->dzdX; f.dzdY = r->dzdY; f.z00 = r->z00;
-                        *(RasterLocal*)(lds_rec + tid * 32) = f;  // in place: this lane is the only reader of the record until the barrier
-                        mode = RASTER_LOCAL32;
-                    }
-                }
-            }
+            if (area && !cover) mode = raster_localise<S>(lds_rec + tid * 32, ox0, oy0);
             if ((uint32_t)tid < cnt) lds_cover[tid] = mode;
             uint32_t incl = area;
 #pragma unroll

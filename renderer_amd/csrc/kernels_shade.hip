@@ -29,6 +29,7 @@
 // weights, filtered colours, the BRDF) and may use rcp / rsq / contraction.
 #include "device_common.h"
 #include "kernels.h"
+#include "raster_common.h"
 
 namespace {
 
@@ -491,40 +492,35 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
 }
 
 #define BLEND_CHUNK 64
-#define BLEND_LIST 256  // fragments a wave collects before it shades and blends them
-#define BLEND_NONE 0xFFFFu
+#define BLEND_NONE 0xFFFFFFFFu
 
-// Blended (MASK + BLEND) draws, back to front: same tile walk as k_raster, the
-// fragments that pass the depth test are blended into the colour target in list
-// order (VulkanRenderer.cpp:862-866, 1059-1062).
+// Blended (MASK + BLEND) draws, back to front (VulkanRenderer.cpp:862-866, 1059-1062), in three kernels so that the
+// expensive part - pbr.frag for every fragment that passes the depth test - runs over the whole GPU at full
+// occupancy instead of inside the few tiles that hold blended geometry:
 //
-// A wave owns an 8x8 quadrant, so the order of the fragments of a pixel is the
-// order in which its wave meets the triangles. Shading each triangle as it is
-// met would run the whole of pbr.frag for the few lanes a small triangle
-// covers; instead the wave appends (triangle, lane, sample mask) to a list in
-// LDS - depth is tested and written at once, it does not depend on shading -
-// and when the list fills up (or the tile is done) shades it densely, one
-// fragment per lane, then every lane walks the chain of its own fragments in
-// order and blends them. No block-level synchronisation is involved.
+//   k_blend_collect  same tile walk as k_raster, one wave per 8x8 quadrant. The order of the fragments of a pixel
+//                    is the order in which its wave meets the triangles; depth is tested and written at once (it
+//                    does not depend on shading) and every passing fragment is appended to a global list as
+//                    (triangle, pixel, sample mask, next fragment of the same pixel). List space is handed out in
+//                    runs of RDR_FRAG_RUN slots: one atomic per block for the first run of each of its waves, one
+//                    per further run; slots a wave leaves unused are marked empty.
+//   k_blend_shade    one lane per list slot, any order: shades the fragment, stores its colour.
+//   k_blend_resolve  one lane per pixel of the tiles with blended triangles: walks the pixel's chain in order,
+//                    blends into the sample colours the opaque pass left, resolves.
 template <int S>
-__global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__ frp, const DView* __restrict__ views,
-                                                      const DShadeTri* __restrict__ tris, const DTriRec* __restrict__ recs,
-                                                      const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
-                                                      const uint32_t* __restrict__ tile_end, uint2* __restrict__ color,
-                                                      uint2* __restrict__ hdr) {
+__global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__ views, const DTriRec* __restrict__ recs,
+                                                       const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
+                                                       const uint32_t* __restrict__ tile_end, uint4* __restrict__ frags,
+                                                       uint32_t* __restrict__ frag_head, uint32_t* __restrict__ frag_used, uint32_t capacity) {
     __shared__ uint32_t lds_rec[BLEND_CHUNK * 32];
     __shared__ uint32_t lds_ids[BLEND_CHUNK];
-    __shared__ float lds_srgb[256];
-    __shared__ uint32_t lds_f_id[4][BLEND_LIST];
-    __shared__ uint16_t lds_f_meta[4][BLEND_LIST];  // lane | sample mask << 8
-    __shared__ uint16_t lds_f_next[4][BLEND_LIST];  // next fragment of the same lane
-    __shared__ float4 lds_f_col[4][BLEND_LIST];
-    const DFrame& fr = *frp;
-    lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
+    __shared__ uint32_t lds_mode[BLEND_CHUNK];  // RASTER_LOCAL32: the record was rewritten with 32-bit tile-local edge functions
+    __shared__ uint32_t lds_first_run;
     const DView vw = views[0];  // the blended view of the batch; its tile lists start at tile_base
     const uint32_t tile = blockIdx.x;
     const uint32_t begin = tile_start[vw.tile_base + tile], end = tile_end[vw.tile_base + tile];
     if (begin >= end) return;
+    if (threadIdx.x == 0) lds_first_run = atomicAdd(frag_used, 4u * RDR_FRAG_RUN);
     const int tx = (int)(tile % vw.tiles_x), ty = (int)(tile / vw.tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qx0 = tx * RDR_TILE + (wave & 1) * 8, qy0 = ty * RDR_TILE + (wave >> 1) * 8;
@@ -532,46 +528,11 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
     const bool in_view = px < (int)vw.w && py < (int)vw.h;
     const size_t plane_px = (size_t)vw.w * vw.h, o = (size_t)py * vw.w + px;
     float z[S];
-    float col[S][4];
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-        z[s] = in_view ? vw.depth[s * plane_px + o] : 0.0f;
-        if (in_view) unpack_half4(color[s * plane_px + o], col[s][0], col[s][1], col[s][2], col[s][3]);
-        else col[s][0] = col[s][1] = col[s][2] = col[s][3] = 0.0f;
-    }
-    uint32_t* f_id = lds_f_id[wave];
-    uint16_t* f_meta = lds_f_meta[wave];
-    uint16_t* f_next = lds_f_next[wave];
-    float4* f_col = lds_f_col[wave];
-    uint32_t n_list = 0;                       // wave-uniform
+    for (int s = 0; s < S; s++) z[s] = in_view ? vw.depth[s * plane_px + o] : 0.0f;
+    uint32_t run_at = 0, run_end = 0;           // wave-uniform: next free slot of this wave's run and its end
+    bool have_run = false;
     uint32_t my_first = BLEND_NONE, my_last = BLEND_NONE;
-
-    auto flush = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        for (uint32_t f = (uint32_t)lane; f < n_list; f += 64u) {
-            const uint32_t fl = f_meta[f] & 63u;
-            float c[4];
-            shade_fragment<true>(fr, lds_srgb, tris[f_id[f]], qx0 + (int)(fl & 7u), qy0 + (int)(fl >> 3), c);
-            f_col[f] = make_float4(c[0], c[1], c[2], c[3]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        for (uint32_t f = my_first; f != BLEND_NONE; f = f_next[f]) {
-            const float4 src = f_col[f];
-            const uint32_t pass = (uint32_t)f_meta[f] >> 8;
-            const float a = src.w;
-#pragma unroll
-            for (int s = 0; s < S; s++)
-                if (pass & (1u << s)) {
-                    col[s][0] = quantize_half(src.x * a + col[s][0] * (1.0f - a));
-                    col[s][1] = quantize_half(src.y * a + col[s][1] * (1.0f - a));
-                    col[s][2] = quantize_half(src.z * a + col[s][2] * (1.0f - a));
-                    col[s][3] = quantize_half(a);
-                }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        n_list = 0;
-        my_first = my_last = BLEND_NONE;
-    };
 
     const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
     for (uint32_t base = begin; base < end; base += BLEND_CHUNK) {
@@ -581,59 +542,143 @@ __global__ void __launch_bounds__(256) k_raster_blend(const DFrame* __restrict__
         __syncthreads();
         for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += 256u) lds_rec[dw] = ((const uint32_t*)(recs + lds_ids[dw >> 5]))[dw & 31u];
         __syncthreads();
+        if (threadIdx.x < cnt) lds_mode[threadIdx.x] = raster_localise<S>(lds_rec + threadIdx.x * 32, tx * RDR_TILE, ty * RDR_TILE);
+        __syncthreads();
+        if (!have_run) { run_at = lds_first_run + (uint32_t)wave * RDR_FRAG_RUN; run_end = run_at + RDR_FRAG_RUN; have_run = true; }
+        const int qlx = (wave & 1) * 8, qly = (wave >> 1) * 8;  // the quadrant inside the tile
         bool hit = false;
         if ((uint32_t)lane < cnt) {
-            const DTriRec* r = (const DTriRec*)(lds_rec + lane * 32);
-            hit = r->px0 <= qx0 + 7 && r->px1 >= qx0 && r->py0 <= qy0 + 7 && r->py1 >= qy0;
+            if (lds_mode[lane] == RASTER_LOCAL32) {
+                const uint32_t b4 = ((const RasterLocal*)(lds_rec + lane * 32))->box4;
+                hit = (int)(b4 & 15u) <= qlx + 7 && (int)((b4 >> 8) & 15u) >= qlx && (int)((b4 >> 4) & 15u) <= qly + 7 && (int)((b4 >> 12) & 15u) >= qly;
+            } else {
+                const DTriRec* r = (const DTriRec*)(lds_rec + lane * 32);
+                hit = r->px0 <= qx0 + 7 && r->px1 >= qx0 && r->py0 <= qy0 + 7 && r->py1 >= qy0;
+            }
         }
         unsigned long long mask = __ballot(hit);
-        const bool last_chunk = base + BLEND_CHUNK >= end;
-        for (;;) {
-            const bool more = mask != 0ull;
-            if (more) {
-                const int ri = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
+        while (mask) {
+            const int ri = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            uint32_t inside = in_view ? (1u << S) - 1u : 0u;
+            double dzdX, dzdY, z00;
+            uint32_t rid;
+            if (lds_mode[ri] == RASTER_LOCAL32) {
+                const RasterLocal* f = (const RasterLocal*)(lds_rec + ri * 32);
+                const int u0 = (qlx + (lane & 7)) << 8, v0 = (qly + (lane >> 3)) << 8;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int Ep = f->C[i] + f->A[i] * u0 + f->B[i] * v0;
+                    if (S == 1) { if (Ep < 0) inside = 0u; }
+                    else {
+#pragma unroll
+                        for (int sm = 0; sm < S; sm++) if (Ep + f->off[i][sm] < 0) inside &= ~(1u << sm);
+                    }
+                }
+                dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id;
+            } else {
                 const DTriRec* r = (const DTriRec*)(lds_rec + ri * 32);
                 const int n = (int)(r->n_view & 255u);
-                const double dzdX = r->dzdX, dzdY = r->dzdY, z00 = r->z00;
-                uint32_t pass = 0;
+                for (int i = 0; i < n; i++) {
+                    const int j = (i + 1 == n) ? 0 : i + 1;
+                    const int Xi = r->X[i], Yi = r->Y[i];
+                    const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
+                    const long long E0 = (long long)dX * (long long)(256 * py - Yi) - (long long)dY * (long long)(256 * px - Xi);
+                    const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const int Px = 256 * px + (S == 1 ? 128 : sxo[s]), Py = 256 * py + (S == 1 ? 128 : syo[s]);
-                    bool inside = in_view;
-                    for (int i = 0; i < n; i++) {
-                        const int j = (i + 1 == n) ? 0 : i + 1;
-                        const int Xi = r->X[i], Yi = r->Y[i];
-                        const int dX = r->X[j] - Xi, dY = r->Y[j] - Yi;
-                        const long long E = (long long)dX * (long long)(Py - Yi) - (long long)dY * (long long)(Px - Xi);
-                        const long long bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
-                        inside = inside && (E >= bias);
-                    }
-                    if (inside) {
-                        float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
-                        zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
-                        if (zz < z[s]) { z[s] = zz; pass |= 1u << s; }
+                    for (int s = 0; s < S; s++) {
+                        const int ax = S == 1 ? 128 : sxo[s], ay = S == 1 ? 128 : syo[s];
+                        if (E0 + ((long long)dX * ay - (long long)dY * ax) < bias) inside &= ~(1u << s);
                     }
                 }
-                const unsigned long long pm = __ballot(pass != 0u);
-                if (pass) {
-                    const uint32_t f = n_list + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-                    f_id[f] = r->id;
-                    f_meta[f] = (uint16_t)((uint32_t)lane | (pass << 8));
-                    f_next[f] = (uint16_t)BLEND_NONE;
-                    if (my_last != BLEND_NONE) f_next[my_last] = (uint16_t)f; else my_first = f;
-                    my_last = f;
-                }
-                n_list += (uint32_t)__popcll(pm);
+                dzdX = r->dzdX; dzdY = r->dzdY; z00 = r->z00; rid = r->id;
             }
-            // the single place where the wave shades and blends what it has collected
-            if (n_list + 64u > BLEND_LIST || (!more && last_chunk && n_list != 0u)) flush();
-            if (!more) break;
+            uint32_t pass = 0;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if (!(inside & (1u << s))) continue;
+                const int Px = 256 * px + (S == 1 ? 128 : sxo[s]), Py = 256 * py + (S == 1 ? 128 : syo[s]);
+                float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
+                zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
+                if (zz < z[s]) { z[s] = zz; pass |= 1u << s; }
+            }
+            const unsigned long long pm = __ballot(pass != 0u);
+            if (!pm) continue;
+            const uint32_t want = (uint32_t)__popcll(pm);
+            if (run_at + want > run_end) {  // this run cannot take them: mark what is left of it empty, take another
+                if (run_at + (uint32_t)lane < run_end) frags[run_at + lane] = make_uint4(BLEND_NONE, 0u, 0u, BLEND_NONE);
+                if (run_at + 64u + (uint32_t)lane < run_end) frags[run_at + 64u + lane] = make_uint4(BLEND_NONE, 0u, 0u, BLEND_NONE);
+                uint32_t fresh = 0;
+                if (lane == 0) fresh = atomicAdd(frag_used, RDR_FRAG_RUN);
+                run_at = __shfl(fresh, 0);
+                run_end = run_at + RDR_FRAG_RUN;
+            }
+            if (pass && run_end <= capacity) {
+                const uint32_t f = run_at + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                frags[f] = make_uint4(rid, (uint32_t)px | ((uint32_t)py << 16), pass, BLEND_NONE);
+                if (my_last != BLEND_NONE) frags[my_last].w = f; else my_first = f;
+                my_last = f;
+            }
+            run_at += want;
         }
+    }
+    // the unused tail of the wave's last run
+    if (have_run && run_end <= capacity) {
+        if (run_at + (uint32_t)lane < run_end) frags[run_at + lane] = make_uint4(BLEND_NONE, 0u, 0u, BLEND_NONE);
+        if (run_at + 64u + (uint32_t)lane < run_end) frags[run_at + 64u + lane] = make_uint4(BLEND_NONE, 0u, 0u, BLEND_NONE);
     }
     if (!in_view) return;
 #pragma unroll
     for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = z[s];
+    frag_head[o] = my_first;
+}
+
+// One lane per fragment slot; the grid is fixed and strides over the slots in use.
+__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_blend_shade(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
+                                                                      const uint4* __restrict__ frags, float4* __restrict__ frag_col,
+                                                                      const uint32_t* __restrict__ frag_used, uint32_t capacity) {
+    __shared__ float lds_srgb[256];
+    const DFrame& fr = *frp;
+    lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
+    __syncthreads();
+    const uint32_t used = min(frag_used[0], capacity);
+    for (uint32_t f = blockIdx.x * 256u + threadIdx.x; f < used; f += gridDim.x * 256u) {
+        const uint4 m = frags[f];
+        if (m.x == BLEND_NONE) continue;
+        float c[4];
+        shade_fragment<true>(fr, lds_srgb, tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c);
+        frag_col[f] = make_float4(c[0], c[1], c[2], c[3]);
+    }
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) k_blend_resolve(const DView* __restrict__ views, const uint32_t* __restrict__ tile_start,
+                                                       const uint32_t* __restrict__ tile_end, const uint4* __restrict__ frags,
+                                                       const float4* __restrict__ frag_col, const uint32_t* __restrict__ frag_head,
+                                                       const uint2* __restrict__ color, uint2* __restrict__ hdr) {
+    const DView vw = views[0];
+    const uint32_t tile = blockIdx.x;
+    if (tile_start[vw.tile_base + tile] >= tile_end[vw.tile_base + tile]) return;
+    const int px = (int)(tile % vw.tiles_x) * RDR_TILE + ((int)threadIdx.x & 15), py = (int)(tile / vw.tiles_x) * RDR_TILE + ((int)threadIdx.x >> 4);
+    if (px >= (int)vw.w || py >= (int)vw.h) return;
+    const size_t plane_px = (size_t)vw.w * vw.h, o = (size_t)py * vw.w + px;
+    float col[S][4];
+#pragma unroll
+    for (int s = 0; s < S; s++) unpack_half4(color[s * plane_px + o], col[s][0], col[s][1], col[s][2], col[s][3]);
+    for (uint32_t f = frag_head[o]; f != BLEND_NONE;) {
+        const uint4 m = frags[f];
+        const float4 src = frag_col[f];
+        const float a = src.w;
+#pragma unroll
+        for (int s = 0; s < S; s++)
+            if (m.z & (1u << s)) {
+                col[s][0] = quantize_half(src.x * a + col[s][0] * (1.0f - a));
+                col[s][1] = quantize_half(src.y * a + col[s][1] * (1.0f - a));
+                col[s][2] = quantize_half(src.z * a + col[s][2] * (1.0f - a));
+                col[s][3] = quantize_half(a);
+            }
+        f = m.w;
+    }
     if (S == 1) {
         hdr[o] = pack_half4(col[0][0], col[0][1], col[0][2], col[0][3]);
     } else {  // multisample resolve: the sample colours are RGBA16F values already
@@ -664,10 +709,20 @@ void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DSh
 }
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
-                         void* hdr) {
+                         void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity) {
     if (!n_tiles) return;
+    (void)hipMemsetAsync(frag_used, 0, 4, s);
     if (samples == 1)
-        hipLaunchKernelGGL(k_raster_blend<1>, dim3(n_tiles), dim3(256), 0, s, fr, view, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color, (uint2*)hdr);
+        hipLaunchKernelGGL(k_blend_collect<1>, dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
+                           frag_used, capacity);
     else
-        hipLaunchKernelGGL(k_raster_blend<4>, dim3(n_tiles), dim3(256), 0, s, fr, view, tris, recs, sorted_vals, tile_start, tile_end, (uint2*)color, (uint2*)hdr);
+        hipLaunchKernelGGL(k_blend_collect<4>, dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
+                           frag_used, capacity);
+    hipLaunchKernelGGL(k_blend_shade, dim3(RDR_BLEND_SHADE_BLOCKS), dim3(256), 0, s, fr, tris, (const uint4*)frags, (float4*)frag_col, frag_used, capacity);
+    if (samples == 1)
+        hipLaunchKernelGGL(k_blend_resolve<1>, dim3(n_tiles), dim3(256), 0, s, view, tile_start, tile_end, (const uint4*)frags, (const float4*)frag_col,
+                           frag_head, (const uint2*)color, (uint2*)hdr);
+    else
+        hipLaunchKernelGGL(k_blend_resolve<4>, dim3(n_tiles), dim3(256), 0, s, view, tile_start, tile_end, (const uint4*)frags, (const float4*)frag_col,
+                           frag_head, (const uint2*)color, (uint2*)hdr);
 }

@@ -141,6 +141,8 @@ struct rdr_ctx {
     PinBuf h_stage, h_read;
     std::vector<DDraw> main_draws;  // opaque draws of the last frame (kept for read-backs)
     uint32_t batch_instances = 0;   // triangle instances of the last raster batch
+    uint64_t blend_pairs = 0, blend_box_pixels = 0;  // of the last batch: (triangle, tile) pairs / box pixels of blended-view triangles
+    DevBuf d_frags, d_frag_col, d_frag_head, d_frag_used;
 
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     rdr_frame_stats stats{};
@@ -424,8 +426,17 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
     launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
     HIP_TRY(c->h_read.ensure(64 + RDR_BINNED_SLOTS * 128));
     HIP_TRY(hipMemcpyAsync(c->h_read.p, counters, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 64, c->d_binned.p, RDR_BINNED_SLOTS * 128, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t n_pairs = c->h_read.as<uint32_t>()[0];
+    // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
+    c->blend_pairs = 0; c->blend_box_pixels = 0;
+    for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
+        const uint32_t* slot = c->h_read.as<uint32_t>() + 16 + k * 32;
+        c->blend_pairs += slot[1];
+        unsigned long long a; memcpy(&a, slot + 2, 8);
+        c->blend_box_pixels += a;
+    }
     for (int k = 0; k < 2; k++) {
         HIP_TRY(c->d_keys[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
         HIP_TRY(c->d_vals[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
@@ -729,7 +740,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_views, &c->d_draws,
                       &c->d_draw_first, &c->d_first_tri, &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start, &c->d_tile_end,
-                      &c->d_counters, &c->d_binned, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_counters, &c->d_binned, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_frag_used, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
@@ -1270,9 +1281,20 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     // ---- blended draws, back to front; resolves its tiles into hdr
     if (have_blend) {
         const uint32_t n_tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
+        // Fragment list slots: every block with blended triangles (at most one per pair, at most n_tiles) starts with
+        // one run per wave; a wave moves to a fresh run only when fewer than 64 slots are left in its run, so the runs
+        // it leaves behind are at least half full; fragments are at most the pixels of the triangles' boxes.
+        const uint64_t blocks = std::min<uint64_t>(n_tiles, c->blend_pairs);
+        const uint64_t capacity = blocks * 4u * RDR_FRAG_RUN + 2u * c->blend_box_pixels + RDR_FRAG_RUN;
+        if (capacity >= (1ull << 31)) return fail(c, RDR_ERR_CAPACITY, "blended pass: the fragment list would need more than 2^31 slots");
+        HIP_TRY(c->d_frags.ensure(capacity * 16));
+        HIP_TRY(c->d_frag_col.ensure(capacity * 16));
+        HIP_TRY(c->d_frag_head.ensure(n * 4));
+        HIP_TRY(c->d_frag_used.ensure(64));
         launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
                             c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
-                            c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p);
+                            c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p, c->d_frag_col.p,
+                            c->d_frag_head.as<uint32_t>(), c->d_frag_used.as<uint32_t>(), (uint32_t)capacity);
         HIP_TRY(hipGetLastError());
     }
 
