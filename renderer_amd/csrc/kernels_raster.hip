@@ -462,12 +462,10 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
         __syncthreads();
         const uint32_t total = lds_prefix[RASTER_CHUNK];
         for (uint32_t wi = (uint32_t)tid; wi < total; wi += (uint32_t)T) {
-            uint32_t lo = 0, hi = cnt;  // largest lo with prefix[lo] <= wi
+            // largest lo with prefix[lo] <= wi; entries past the last record hold the total, which is > wi
+            uint32_t lo = 0;
 #pragma unroll
-            for (int it = 0; (1 << it) < RASTER_CHUNK; it++) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (hi - lo > 1u) { if (lds_prefix[mid] <= wi) lo = mid; else hi = mid; }
-            }
+            for (int step = RASTER_CHUNK / 2; step >= 1; step >>= 1) lo += lds_prefix[lo + step] <= wi ? (uint32_t)step : 0u;
             const uint32_t local = wi - lds_prefix[lo];
             const uint32_t mode = lds_cover[lo];
             uint32_t inside = (1u << S) - 1u;
@@ -478,12 +476,12 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
                 const RasterLocal* f = (const RasterLocal*)(lds_rec + lo * 32);
                 const uint32_t box = f->box;
                 const uint32_t bw = ((box >> 8) & 15u) + 1u;
-                const uint32_t row = (local * (box >> 12)) >> 16;        // local / bw, exact for local < 256
-                const int xl = (int)(box & 15u) + (int)(local - row * bw), yl = (int)((box >> 4) & 15u) + (int)row;
+                const uint32_t row = __umul24(local, box >> 12) >> 16;   // local / bw, exact for local < 256
+                const int xl = (int)(box & 15u) + (int)(local - __umul24(row, bw)), yl = (int)((box >> 4) & 15u) + (int)row;
                 x = ox0 + xl; y = oy0 + yl;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    const int Ep = f->C[i] + f->A[i] * (xl << 8) + f->B[i] * (yl << 8);
+                    const int Ep = f->C[i] + __mul24(f->A[i], xl << 8) + __mul24(f->B[i], yl << 8);  // |A|, |B| <= 2^18
                     if (S == 1) { if (Ep < 0) inside = 0u; }
                     else {
 #pragma unroll

@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__
                 const int u0 = (qlx + (lane & 7)) << 8, v0 = (qly + (lane >> 3)) << 8;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    const int Ep = f->C[i] + f->A[i] * u0 + f->B[i] * v0;
+                    const int Ep = f->C[i] + __mul24(f->A[i], u0) + __mul24(f->B[i], v0);  // |A|, |B| <= 2^18
                     if (S == 1) { if (Ep < 0) inside = 0u; }
                     else {
 #pragma unroll

@@ -14,7 +14,7 @@
 #define SCAN_BLOCK 256
 #define SCAN_ITEMS 16
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
-#define SORT_ROUNDS 32
+#define SORT_ROUNDS 16
 #define SORT_CHUNK (64 * SORT_ROUNDS)
 #define SORT_MAX_BINS 512
 
@@ -126,10 +126,20 @@ __global__ void __launch_bounds__(64) k_sort_scatter(const uint32_t* __restrict_
     __syncthreads();
     const uint32_t base = blockIdx.x * SORT_CHUNK;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // the rounds depend on each other through offs[], so their loads are issued up front: one memory latency for
+    // the chunk instead of one per round
+    uint32_t kreg[SORT_ROUNDS], vreg[SORT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; r++) {
+        const uint32_t i = base + r * 64 + lane;
+        kreg[r] = i < n ? keys[i] : 0u;
+        vreg[r] = i < n ? vals[i] : 0u;
+    }
+#pragma unroll
     for (int r = 0; r < SORT_ROUNDS; r++) {
         const uint32_t i = base + r * 64 + lane;
         const bool valid = i < n;
-        const uint32_t key = valid ? keys[i] : 0u, val = valid ? vals[i] : 0u;
+        const uint32_t key = kreg[r], val = vreg[r];
         const uint32_t digit = (key >> shift) & (bins - 1u);
         // lanes holding the same digit as this lane
         unsigned long long same = __ballot(valid);
