@@ -58,3 +58,37 @@ def test_small_scene_parity(orc_capi, hip_capi, msaa):
     # shading: tolerance on the tonemapped output
     hp.assert_image_close(out_o, out_h)
     assert abs(avg_o - avg_h) < 1e-3
+
+
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_many_blended_layers(orc_capi, hip_capi, msaa):
+    """Seven screen-filling translucent and alpha-tested layers in front of a floor, some of them huge triangles that
+    are clipped by the near plane and the guard band: every 8x8 quadrant collects several hundred blended fragments
+    (its list space is extended many times), blend order is the back-to-front draw order, and the layers exercise
+    the clipped-polygon path of the blended pass next to the 32-bit edge functions of the small triangles."""
+    W, H = 200, 120
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, **hp.small_settings(msaa))
+    for r in (ro, rh):
+        tex = scenes.material_textures(r, 32, 91, tint=(0.9, 0.9, 0.9), alpha=0.25 + 0.5 * scenes.value_noise(32, 5, octaves=2, base=4))
+        r.add_mesh([scenes.upload_primitive(r, scenes.plane(20, 20, 4, 4, uv_scale=4.0), scenes.make_material(tex))])
+        for k in range(7):
+            big = k % 3 == 2   # one quad of two huge triangles instead of a fine grid
+            quad = scenes.plane(400.0 if big else 9.0, 400.0 if big else 6.0, 1 if big else 12, 1 if big else 8, uv_scale=60.0 if big else 2.0)
+            quad = quad.transformed(scenes.translation(0.1 * k, 1.2, 2.5 - 0.45 * k) @ scenes.rotation_x(np.pi / 2 + 0.05 * k))
+            mode = scenes.B.ALPHA_MASK if k % 4 == 1 else scenes.B.ALPHA_BLEND
+            mat = scenes.make_material(tex, base_color=(0.4 + 0.08 * k, 1.0 - 0.1 * k, 0.6, 0.35 + 0.05 * k), alpha_mode=mode, alpha_cutoff=0.45,
+                                       metallic=0.2, roughness=0.6)
+            r.add_mesh([scenes.upload_primitive(r, quad, mat, scenes.B.UINT16)])
+        r.set_brdf_lut(scenes.brdf_lut(32, 32))
+        r.set_environment_map(scenes.sky_faces(16))
+        r.set_camera(position=(0.0, 1.3, 4.6), euler=(-0.05, 0.0, 0.0))
+        r.set_lights([((1.5, 2.2, 3.5), (30.0, 24.0, 18.0), True)], scenes.default_directional_light())
+    out_o, _ = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    out_h, _ = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    assert np.array_equal(ro.read_depth(), rh.read_depth())
+    hdr_o, hdr_h = ro.read_hdr(), rh.read_hdr()
+    assert np.allclose(hdr_o[..., 3], hdr_h[..., 3], rtol=2e-3, atol=1e-4), "alpha is the last blended fragment's (a filtered texel: 1-2 half ulps)"
+    hp.assert_image_close(out_o, out_h)
+    assert hp.psnr(out_o, out_h) > 45
+    # the layers are really there: the frame differs from the same scene without them
+    assert (np.abs(hdr_o[..., 3] - 1.0) > 1e-3).mean() > 0.5
