@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -147,6 +148,8 @@ struct rdr_ctx {
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     rdr_frame_stats stats{};
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_pairs = nullptr;  // the pair count of the batch being binned has reached the host
+    PinBuf h_frame;                 // staging of DFrame + lights (h_stage is busy with the batch tables at that point)
 };
 
 namespace {
@@ -378,7 +381,7 @@ int create_image(rdr_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h, bool s
 
 // Runs set-up -> bin -> sort for one batch of views. On return the sorted
 // triangle lists of every tile are in d_vals[*cur] / d_tile_start / d_tile_end.
-int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
+int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std::function<int()>& after_scan) {
     uint32_t n_tiles = 0;
     for (DView& v : b.views) {
         v.tiles_x = (v.w + RDR_TILE - 1) / RDR_TILE; v.tiles_y = (v.h + RDR_TILE - 1) / RDR_TILE;
@@ -427,7 +430,9 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
     HIP_TRY(c->h_read.ensure(64 + RDR_BINNED_SLOTS * 128));
     HIP_TRY(hipMemcpyAsync(c->h_read.p, counters, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 64, c->d_binned.p, RDR_BINNED_SLOTS * 128, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventRecord(c->ev_pairs, c->stream));
+    if (after_scan) RDR_TRY(after_scan());
+    HIP_TRY(hipEventSynchronize(c->ev_pairs));
     const uint32_t n_pairs = c->h_read.as<uint32_t>()[0];
     // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
     c->blend_pairs = 0; c->blend_box_pixels = 0;
@@ -459,11 +464,13 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur) {
     return RDR_OK;
 }
 
-int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr) {
+// `after_scan`, if given, runs once set-up and the pair scan are enqueued and before the host waits for the pair
+// count: work enqueued there keeps the GPU busy while the host sizes the pair buffers.
+int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::function<int()>& after_scan = nullptr) {
     if (b.views.empty()) return RDR_OK;
     uint32_t n_tiles = 0;
     int cur = 0;
-    RDR_TRY(bin_batch(c, b, &n_tiles, &cur));
+    RDR_TRY(bin_batch(c, b, &n_tiles, &cur, after_scan));
     if (out_cur) *out_cur = cur;
     // tile range per sample count (views are laid out in order, so each is one interval); tiles of views this
     // kernel does not rasterise (load == 2) are left out
@@ -704,6 +711,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     memset(&c->dir_light, 0, sizeof c->dir_light);
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
     for (int i = 0; i < 10 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_pairs, hipEventDisableTiming) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
     std::vector<float> tables(768);
     for (int i = 0; i < 256; i++) {
@@ -746,6 +754,8 @@ void rdr_destroy(rdr_ctx* c) {
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
     for (int i = 0; i < 10; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
+    c->h_frame.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1197,26 +1207,22 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     const bool have_blend = n_blend_draws != 0;
     if (have_blend) b.views.push_back(make_view(c->d_depth.as<float>(), nullptr, W, H, S, 2, 2));
     c->stats.draws_main = (uint32_t)(n_main_draws + n_blend_draws);
-    int cur = 0;
-    RDR_TRY(raster_batch(c, b, &cur));
-    if (have_blend) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    // triangle records of a view are contiguous in d_recs, in visibility-id order
+    // Frame constants, then the vertex stage of the main view's triangles: enqueued from inside the batch, right after
+    // its pair scan (which is all k_shade_setup needs from it), so that they run while the host waits for the pair count.
     uint32_t main_first_instance = 0, n_main_tris = 0, blend_first_instance = 0, n_blend_tris = 0;
-    if (n_main_draws) {
-        main_first_instance = b.draws[first_main_draw].first_instance;
-        const DDraw& last = b.draws[first_blend_draw - 1];
-        n_main_tris = last.first_tri_id + c->prims[last.prim].tri_count;
-    }
-    if (have_blend) {
-        blend_first_instance = b.draws[first_blend_draw].first_instance;
-        const DDraw& last = b.draws.back();
-        n_blend_tris = last.first_tri_id + c->prims[last.prim].tri_count;
-    }
-    const uint32_t blend_tile_base = have_blend ? b.views.back().tile_base : 0u;
-
-    // ---- frame constants
-    {
+    DShadeTri *tris_main = nullptr, *tris_blend = nullptr;
+    auto enqueue_shade_setup = [&]() -> int {
+        // triangle records of a view are contiguous in d_recs, in visibility-id order
+        if (n_main_draws) {
+            main_first_instance = b.draws[first_main_draw].first_instance;
+            const DDraw& last = b.draws[first_blend_draw - 1];
+            n_main_tris = last.first_tri_id + c->prims[last.prim].tri_count;
+        }
+        if (have_blend) {
+            blend_first_instance = b.draws[first_blend_draw].first_instance;
+            const DDraw& last = b.draws.back();
+            n_blend_tris = last.first_tri_id + c->prims[last.prim].tri_count;
+        }
         DFrame fr;
         memset(&fr, 0, sizeof fr);
         fr.W = W; fr.H = H; fr.samples = S; fr.n_lights = (uint32_t)c->lights.size();
@@ -1248,29 +1254,37 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         fr.pos = c->d_pos.as<float4>(); fr.attr = c->d_attr.as<DVertexAttr>(); fr.idx = c->d_idx.as<uint32_t>();
         fr.srgb_decode = c->d_tables.as<float>(); fr.unorm_decode = c->d_tables.as<float>() + 256;
         fr.tex_white = 0; fr.tex_normal = 1;
-        // the staging buffer is free again: bin_batch synchronised after its uploads
+        // its own pinned block: the previous frame's copy out of it finished before that frame's pair count arrived
         const size_t sz_l = dl.size() * sizeof(DPointLight);
-        HIP_TRY(c->h_stage.ensure(sizeof(DFrame) + sz_l + 64));
-        uint8_t* st = c->h_stage.as<uint8_t>();
+        HIP_TRY(c->h_frame.ensure(sizeof(DFrame) + sz_l + 64));
+        uint8_t* st = c->h_frame.as<uint8_t>();
         memcpy(st, &fr, sizeof fr);
         memcpy(st + sizeof fr, dl.data(), sz_l);
         HIP_TRY(hipMemcpyAsync(c->d_frame.p, st, sizeof fr, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_lights.p, st + sizeof fr, sz_l, hipMemcpyHostToDevice, c->stream));
-    }
 
-    // ---- opaque shading + skybox. d_draws / d_first_tri still hold the whole batch; a view's draws are a slice.
+        // d_draws / d_first_tri hold the whole batch; a view's draws are a slice
+        HIP_TRY(c->d_shade_tris.ensure(std::max<size_t>((size_t)n_main_tris + n_blend_tris, 1) * sizeof(DShadeTri)));
+        tris_main = c->d_shade_tris.as<DShadeTri>();
+        tris_blend = tris_main + n_main_tris;
+        launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_main_draw, c->d_first_tri.as<uint32_t>() + first_main_draw,
+                           (uint32_t)n_main_draws, n_main_tris, c->d_pair_count.as<uint32_t>() + main_first_instance,
+                           c->batch_instances - main_first_instance, c->d_counters.as<uint32_t>(), tris_main);
+        if (have_blend)
+            launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_blend_draw,
+                               c->d_first_tri.as<uint32_t>() + first_blend_draw, (uint32_t)n_blend_draws, n_blend_tris,
+                               c->d_pair_count.as<uint32_t>() + blend_first_instance, c->batch_instances - blend_first_instance,
+                               c->d_counters.as<uint32_t>(), tris_blend);
+        return RDR_OK;
+    };
+    int cur = 0;
+    RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup));
+    if (have_blend) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    const uint32_t blend_tile_base = have_blend ? b.views.back().tile_base : 0u;
+
+    // ---- opaque shading + skybox
     if (S == 4 && have_blend) HIP_TRY(c->d_samples.ensure(n * 4 * 8));
-    HIP_TRY(c->d_shade_tris.ensure(std::max<size_t>((size_t)n_main_tris + n_blend_tris, 1) * sizeof(DShadeTri)));
-    DShadeTri* tris_main = c->d_shade_tris.as<DShadeTri>();
-    DShadeTri* tris_blend = tris_main + n_main_tris;
-    launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_main_draw, c->d_first_tri.as<uint32_t>() + first_main_draw,
-                       (uint32_t)n_main_draws, n_main_tris, c->d_pair_count.as<uint32_t>() + main_first_instance,
-                       c->batch_instances - main_first_instance, c->d_counters.as<uint32_t>(), tris_main);
-    if (have_blend)
-        launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_blend_draw,
-                           c->d_first_tri.as<uint32_t>() + first_blend_draw, (uint32_t)n_blend_draws, n_blend_tris,
-                           c->d_pair_count.as<uint32_t>() + blend_first_instance, c->batch_instances - blend_first_instance,
-                           c->d_counters.as<uint32_t>(), tris_blend);
     HIP_TRY(hipEventRecord(c->ev[6], c->stream));
     launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
                         (S == 4 && have_blend) ? c->d_samples.p : nullptr, c->d_tile_start.as<uint32_t>() + blend_tile_base,
