@@ -11,11 +11,12 @@
 //             key = global tile id                        -> pairs
 //   (stable radix sort of the pairs by tile: kernels_sort.hip)
 //   k_ranges  list boundaries per tile
-//   k_raster  one 256-thread block per 16x16 tile: records staged through LDS
-//             64 at a time, the (triangle, pixel) items of their pixel boxes
-//             spread over the threads; edge functions are exact 64-bit
-//             integers, depth is a double-precision plane rounded to float, the
-//             LESS test is an LDS atomic min on (depth, triangle id).
+//   k_raster  one block per 16x16 tile: records staged through LDS 64 at a
+//             time, the (triangle, pixel) items of their pixel boxes spread
+//             over the threads; edge functions are exact integers (32-bit
+//             relative to the tile where that is provably the same, 64-bit
+//             otherwise), depth is a double-precision plane rounded to float,
+//             the LESS test is an LDS atomic min on (depth, triangle id).
 //
 // Bit-exactness with the CPU checker rests on three things: the fma chains
 // are written out, the edge functions are integer, and double arithmetic is

@@ -1,6 +1,7 @@
 // Main colour pass from the visibility buffer: basic.vert + pbr.frag per
-// pixel, the skybox (env.vert + env.frag), the in-order blended pass and the
-// multisample resolve.
+// pixel, the skybox (env.vert + env.frag), the in-order blended pass
+// (k_blend_collect -> k_blend_shade -> k_blend_resolve, described above them)
+// and the multisample resolve.
 //
 // Reference: Renderer/shaders/basic.vert:36-49, pbr.frag:93-269, env.vert:22-26,
 // env.frag:10-17; pass order and blend state Renderer/VulkanRenderer.cpp:1043-1065,
@@ -9,7 +10,7 @@
 // Structure of the opaque pass (k_shade_setup -> k_shade_opaque):
 //  * k_shade_setup, one thread per main-view triangle that survived set-up:
 //    runs basic.vert for its three vertices once and stores the outputs plus
-//    the perspective-correct barycentric planes in a 256-byte DShadeTri, so a
+//    the perspective-correct barycentric planes in a 384-byte DShadeTri, so a
 //    fragment never re-transforms vertices.
 //  * k_shade_opaque, one 256-thread block per 16x16 tile. With 4x MSAA a pixel
 //    is shaded once per DISTINCT triangle among its samples; looping over
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 // Opaque draws + skybox. S == 1: writes hdr. S == 4: resolves straight into
 // hdr, except in tiles whose blended-pass triangle list is not empty
 // (blend_start < blend_end): those keep their four sample colours in
-// `samples_out` for k_raster_blend, which resolves them afterwards.
+// `samples_out` for the blended pass, which resolves them afterwards.
 #ifndef RDR_SHADE_WAVES
 #define RDR_SHADE_WAVES 4  // waves per SIMD the register allocation is held to (128 VGPRs)
 #endif

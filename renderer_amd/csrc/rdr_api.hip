@@ -1187,7 +1187,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
 
     // ---- shadow views, the main opaque view and the blended draws of the main view, binned as one batch.
     // The blended "view" shares the main depth target; k_raster leaves its tiles alone (load == 2) and
-    // k_raster_blend walks them after the opaque shading.
+    // k_blend_collect walks them after the opaque shading.
     Batch b;
     if (c->lights_set) {
         RDR_TRY(point_shadow_views(c, cam_pos, b));
