@@ -480,14 +480,17 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
                 const uint32_t row = __umul24(local, box >> 12) >> 16;   // local / bw, exact for local < 256
                 const int xl = (int)(box & 15u) + (int)(local - __umul24(row, bw)), yl = (int)((box >> 4) & 15u) + (int)row;
                 x = ox0 + xl; y = oy0 + yl;
+                int Ep[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const int Ep = f->C[i] + __mul24(f->A[i], xl << 8) + __mul24(f->B[i], yl << 8);  // |A|, |B| <= 2^18
-                    if (S == 1) { if (Ep < 0) inside = 0u; }
-                    else {
+                for (int i = 0; i < 3; i++) Ep[i] = f->C[i] + __mul24(f->A[i], xl << 8) + __mul24(f->B[i], yl << 8);  // |A|, |B| <= 2^18
+                // a sample is outside when any of its three edge values is negative: the sign bit of their OR
+                if (S == 1) { if ((Ep[0] | Ep[1] | Ep[2]) < 0) inside = 0u; }
+                else {
+                    uint32_t outside = 0u;
 #pragma unroll
-                        for (int sm = 0; sm < S; sm++) if (Ep + f->off[i][sm] < 0) inside &= ~(1u << sm);
-                    }
+                    for (int sm = 0; sm < S; sm++)
+                        outside |= ((uint32_t)((Ep[0] + f->off[0][sm]) | (Ep[1] + f->off[1][sm]) | (Ep[2] + f->off[2][sm])) >> 31) << sm;
+                    inside &= ~outside;
                 }
                 dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id;
             } else {

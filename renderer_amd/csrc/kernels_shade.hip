@@ -567,14 +567,17 @@ __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__
             if (lds_mode[ri] == RASTER_LOCAL32) {
                 const RasterLocal* f = (const RasterLocal*)(lds_rec + ri * 32);
                 const int u0 = (qlx + (lane & 7)) << 8, v0 = (qly + (lane >> 3)) << 8;
+                int Ep[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const int Ep = f->C[i] + __mul24(f->A[i], u0) + __mul24(f->B[i], v0);  // |A|, |B| <= 2^18
-                    if (S == 1) { if (Ep < 0) inside = 0u; }
-                    else {
+                for (int i = 0; i < 3; i++) Ep[i] = f->C[i] + __mul24(f->A[i], u0) + __mul24(f->B[i], v0);  // |A|, |B| <= 2^18
+                // a sample is outside when any of its three edge values is negative: the sign bit of their OR
+                if (S == 1) { if ((Ep[0] | Ep[1] | Ep[2]) < 0) inside = 0u; }
+                else {
+                    uint32_t outside = 0u;
 #pragma unroll
-                        for (int sm = 0; sm < S; sm++) if (Ep + f->off[i][sm] < 0) inside &= ~(1u << sm);
-                    }
+                    for (int sm = 0; sm < S; sm++)
+                        outside |= ((uint32_t)((Ep[0] + f->off[0][sm]) | (Ep[1] + f->off[1][sm]) | (Ep[2] + f->off[2][sm])) >> 31) << sm;
+                    inside &= ~outside;
                 }
                 dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id;
             } else {
