@@ -92,3 +92,50 @@ def test_many_blended_layers(orc_capi, hip_capi, msaa):
     assert hp.psnr(out_o, out_h) > 45
     # the layers are really there: the frame differs from the same scene without them
     assert (np.abs(hdr_o[..., 3] - 1.0) > 1e-3).mean() > 0.5
+
+
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_degenerate_scenes(orc_capi, hip_capi, msaa):
+    """What a caller can legitimately leave out: no mesh at all (sky only), no lights set, no environment and no
+    BRDF table (black sky, no image-based term), and a mesh entirely behind the camera. Sizes that are not multiples
+    of the 16-pixel tile."""
+    W, H = 173, 99
+    frame = dict(exposure_mode=1, temporal_luminance=0.5)
+
+    def pair():
+        return hp.make_pair(orc_capi, hip_capi, W, H, **hp.small_settings(msaa))
+
+    # 1: nothing but the environment
+    ro, rh = pair()
+    for r in (ro, rh):
+        r.set_environment_map(scenes.sky_faces(16))
+        r.set_brdf_lut(scenes.brdf_lut(16, 16))
+        r.set_camera(position=(0, 1, 3), euler=(0.2, 0.4, 0.0))
+    a, la = ro.render_frame(**frame)
+    b, lb = rh.render_frame(**frame)
+    assert (ro.read_depth() == 1.0).all() and np.array_equal(ro.read_depth(), rh.read_depth())
+    assert (rh.read_visibility() == 0xFFFFFFFF).all()
+    hp.assert_image_close(a, b)
+    assert a[..., :3].std() > 2, "the sky is visible"
+    ro.close(); rh.close()
+
+    # 2: geometry, but neither lights nor environment nor table: emissive and nothing else
+    ro, rh = pair()
+    for r in (ro, rh):
+        tex = scenes.material_textures(r, 16, 7)
+        r.add_mesh([scenes.upload_primitive(r, scenes.box(1.0, 1.0, 1.0, 2), scenes.make_material(tex, emissive=(0.5, 0.4, 0.3)), scenes.B.UINT16)])
+        r.set_camera(position=(1.2, 1.0, 2.5), euler=(-0.3, 0.45, 0.0))
+    a, _ = ro.render_frame(**frame)
+    b, _ = rh.render_frame(**frame)
+    assert np.array_equal(ro.read_depth(), rh.read_depth()) and np.array_equal(ro.read_visibility(), rh.read_visibility())
+    hp.assert_image_close(a, b)
+    assert (ro.read_depth() < 1.0).any()
+    # 3: the same box behind the camera: every triangle is clipped away or culled
+    for r in (ro, rh):
+        r.set_camera(position=(0.0, 0.0, -3.0), euler=(0.0, 0.0, 0.0))
+    a, _ = ro.render_frame(**frame)
+    b, _ = rh.render_frame(**frame)
+    assert (rh.read_depth() == 1.0).all() and np.array_equal(a, b)
+    so, sh = ro.frame_stats(), rh.frame_stats()
+    assert so.triangles_binned == sh.triangles_binned == 0
+    ro.close(); rh.close()
