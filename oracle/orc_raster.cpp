@@ -73,12 +73,14 @@ static bool setup_triangle(const Draw& d, const Primitive& pr, size_t t, int W, 
     // ---- clip
     ClipV poly[12], tmp[12];
     int n = 3;
+    bool clipped = false;
     poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2];
     for (int plane = 0; plane < 6; plane++) {
         int outside = 0;
         for (int i = 0; i < 3; i++) outside += plane_dist(cv[i], plane, kx, ky) < 0.0f;
         if (outside == 0) continue;
         if (outside == 3) return false;
+        clipped = true;
         int m = 0;
         for (int i = 0; i < n; i++) {
             const ClipV& a = poly[i];
@@ -146,6 +148,29 @@ static bool setup_triangle(const Draw& d, const Primitive& pr, size_t t, int W, 
     ix1 = std::min(ix1, W - 1); iy1 = std::min(iy1, H - 1);
     if (ix0 > ix1 || iy0 > iy1) return false;
     r.ix0 = ix0; r.ix1 = ix1; r.iy0 = iy0; r.iy1 = iy1;
+
+    // ---- an unclipped triangle at most 32 pixels across whose box holds at most 16 pixels and which covers none of their samples is dropped
+    // here (it could never write anything); this only keeps the "binned" statistic comparable with the HIP set-up,
+    // which drops such triangles before they cost a record and tile pairs
+    if (!clipped && (ix1 - ix0 + 1) * (iy1 - iy0 + 1) <= 16 && maxX - minX <= 8192 && maxY - minY <= 8192) {
+        static const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
+        bool covered = false;
+        for (int py = iy0; py <= iy1 && !covered; py++)
+            for (int px = ix0; px <= ix1 && !covered; px++)
+                for (int sm = 0; sm < (S == 1 ? 1 : 4) && !covered; sm++) {
+                    const int64_t Px = 256ll * px + (S == 1 ? 128 : sxo[sm]), Py = 256ll * py + (S == 1 ? 128 : syo[sm]);
+                    bool inside = true;
+                    for (int i = 0; i < 3; i++) {
+                        const int j = (i + 1) % 3;
+                        const int64_t dX = X[j] - X[i], dY = Y[j] - Y[i];
+                        const int64_t E = dX * (Py - Y[i]) - dY * (Px - X[i]);
+                        const int64_t bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+                        inside = inside && E >= bias;
+                    }
+                    covered = inside;
+                }
+        if (!covered) return false;
+    }
 
     // ---- depth plane from the unclipped homogeneous vertices: a x + b y + c w = z
     const double x0 = cv[0].x, y0 = cv[0].y, z0 = cv[0].z, w0 = cv[0].w;

@@ -87,6 +87,36 @@ RDR_DEV uint32_t finish_record(const int32_t* X, const int32_t* Y, int n_in, con
     ix1 = min(ix1, W - 1); iy1 = min(iy1, H - 1);
     if (ix0 > ix1 || iy0 > iy1) return 0;
 
+    // ---- a triangle whose box is a few pixels may cover no sample at all (sub-pixel triangles of dense meshes,
+    // slivers of surfaces seen edge-on): the rasteriser's own test, on the at most 16 pixels of the box, settles it
+    // here, before the triangle costs a record, tile pairs and a place in the tile lists.
+    // With the triangle itself at most 32 pixels across every term below is under 2^28, so 32-bit integers hold them.
+    if (FIXED == 3 && (ix1 - ix0 + 1) * (iy1 - iy0 + 1) <= 16 && maxX - minX <= 8192 && maxY - minY <= 8192) {
+        const bool flip = area2 < 0;
+        int E0[3], ex[3], ey[3], es[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            // edge i of the polygon oriented so that its interior has positive edge functions
+            const int a = flip ? 2 - i : i, b2 = flip ? (2 - i + 2) % 3 : (i + 1) % 3;
+            const int dX = X[b2] - X[a], dY = Y[b2] - Y[a];
+            const int bias = ((dY < 0) || (dY == 0 && dX > 0)) ? 0 : 1;
+            E0[i] = dX * (256 * iy0 - Y[a]) - dY * (256 * ix0 - X[a]) - bias;
+            ex[i] = -dY * 256; ey[i] = dX * 256;
+            const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
+#pragma unroll
+            for (int sm = 0; sm < 4; sm++) es[i][sm] = S == 1 ? dX * 128 - dY * 128 : dX * syo[sm] - dY * sxo[sm];
+        }
+        bool covered = false;
+        const int ns = S == 1 ? 1 : 4;
+        for (int py = 0; py <= iy1 - iy0 && !covered; py++)
+            for (int px = 0; px <= ix1 - ix0 && !covered; px++) {
+                const int e0 = E0[0] + ex[0] * px + ey[0] * py, e1 = E0[1] + ex[1] * px + ey[1] * py, e2 = E0[2] + ex[2] * px + ey[2] * py;
+                for (int sm = 0; sm < ns; sm++)
+                    if (((e0 + es[0][sm]) | (e1 + es[1][sm]) | (e2 + es[2][sm])) >= 0) covered = true;
+            }
+        if (!covered) return 0;
+    }
+
     // ---- depth plane a x + b y + c w = z through the unclipped vertices
     const double x0 = cv[0].x, y0 = cv[0].y, z0 = cv[0].z, w0 = cv[0].w;
     const double x1 = cv[1].x, y1 = cv[1].y, z1 = cv[1].z, w1 = cv[1].w;
