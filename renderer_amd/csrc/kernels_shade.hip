@@ -212,7 +212,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     const DShadeTri& mt = T;  // material block and texture descriptors travel with the triangle
 
 #ifndef RDR_DIAG
-#define RDR_DIAG 0  // diagnostic builds only: bit 0 no textures, bit 1 no directional light, bit 2 no IBL, bit 3 nothing after interpolation
+#define RDR_DIAG 0  // diagnostic builds only: bit 0 no textures, bit 1 no directional light, bit 2 no IBL, bit 3 nothing after interpolation, bit 4 no point lights, bit 5 no point-light shadow lookups
 #endif
     if (RDR_DIAG & 8) { out[0] = P.x + Nv.x + Tv.y + Bv.z; out[1] = u0 + dudx; out[2] = v0 + dvdy + dudy + dvdx; out[3] = 1.0f; return; }
     // ---- pbr.frag main()
@@ -258,7 +258,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     const float c0 = 100.0f / (100.0f - 0.1f), c1 = (100.0f * 0.1f) / (100.0f - 0.1f);
     // Four lights at a time, in two phases: first the light vectors and the shadow-map lookups of all four (their
     // loads overlap), then the BRDFs. Whether a light casts shadows is uniform, so that branch costs nothing.
-    for (uint32_t base = 0; base < fr.n_lights; base += 4u) {
+    for (uint32_t base = 0; base < ((RDR_DIAG & 16) ? 0u : fr.n_lights); base += 4u) {
         F3 Lv[4];
         float d2[4], sh[4];
 #pragma unroll
@@ -269,7 +269,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
             Lv[j] = f3(pl.px, pl.py, pl.pz) - P;
             d2[j] = dot3(Lv[j], Lv[j]);  // distance^2
             sh[j] = 1.0f;
-            if ((pl.flags & 1u) && (pl.flags & 2u)) {
+            if ((pl.flags & 1u) && (pl.flags & 2u) && !(RDR_DIAG & 32)) {
                 const float lightDepth = fmaxf(fabsf(Lv[j].x), fmaxf(fabsf(Lv[j].y), fabsf(Lv[j].z))) - 0.05f;
                 const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
                 const float shadowTest = shadow_cube(fr, pl.slot, -Lv[j].x, -Lv[j].y, -Lv[j].z, ref);
@@ -382,6 +382,9 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 }
 
 #define SHADE_NO_FRAGMENT 0xFFu
+#ifndef RDR_XCD_SQ_LOG2
+#define RDR_XCD_SQ_LOG2 3
+#endif
 
 // Opaque draws + skybox. S == 1: writes hdr. S == 4: resolves straight into
 // hdr, except in tiles whose blended-pass triangle list is not empty
@@ -394,7 +397,8 @@ template <int S>
 __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
                                                       const float* __restrict__ depth, const uint32_t* __restrict__ vis,
                                                       uint2* __restrict__ hdr, uint2* __restrict__ samples_out,
-                                                      const uint32_t* __restrict__ blend_start, const uint32_t* __restrict__ blend_end) {
+                                                      const uint32_t* __restrict__ blend_start, const uint32_t* __restrict__ blend_end,
+                                                      uint32_t n_tiles) {
     __shared__ float lds_srgb[256];
     __shared__ uint32_t lds_frag_id[256 * S];   // triangle id of fragment f
     __shared__ uint8_t lds_frag_px[256 * S];    // its pixel = the thread index that owns the pixel
@@ -403,7 +407,19 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
     const DFrame& fr = *frp;
     lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
     const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
-    const int tx = (int)(blockIdx.x % tiles_x), ty = (int)(blockIdx.x / tiles_x);
+    int tx, ty;
+    {
+#ifndef RDR_NO_XCD_MAP
+        // 8x8-tile squares, dealt round-robin to the dies: block b belongs to die b % 8 and is its (b / 8)-th block
+        const uint32_t Q = RDR_XCD_SQ_LOG2, side = 1u << Q;
+        const uint32_t k = blockIdx.x >> 3, sq = (k >> (2u * Q)) * 8u + (blockIdx.x & 7u), in = k & (side * side - 1u), sq_x = (tiles_x + side - 1u) >> Q;
+        tx = (int)((sq % sq_x) * side + (in & (side - 1u))); ty = (int)((sq / sq_x) * side + (in >> Q));
+#else
+        tx = (int)(blockIdx.x % tiles_x); ty = (int)(blockIdx.x / tiles_x);
+#endif
+    }
+    if ((uint32_t)tx >= tiles_x || (uint32_t)ty * tiles_x + (uint32_t)tx >= n_tiles) return;
+    const uint32_t tile = (uint32_t)ty * tiles_x + (uint32_t)tx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool in_view = px < (int)fr.W && py < (int)fr.H;
@@ -473,7 +489,7 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
     uint2 sc[S];
 #pragma unroll
     for (int s = 0; s < S; s++) sc[s] = slot[s] == SHADE_NO_FRAGMENT ? sky_packed : lds_frag_col[before + slot[s]];
-    const bool keep_samples = S > 1 && samples_out && blend_start[blockIdx.x] < blend_end[blockIdx.x];
+    const bool keep_samples = S > 1 && samples_out && blend_start[tile] < blend_end[tile];
     if (S == 1) {
         hdr[o] = sc[0];
     } else if (keep_samples) {
@@ -706,10 +722,16 @@ void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, con
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H) {
     const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
+#ifndef RDR_NO_XCD_MAP
+    const uint32_t side = 1u << RDR_XCD_SQ_LOG2;
+    const uint32_t grid = ((((W + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) * (((H + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) + 7u) / 8u * 8u * side * side;
+#else
+    const uint32_t grid = tiles;
+#endif
     if (samples == 1)
-        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end);
+        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(grid), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
     else
-        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(tiles), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end);
+        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(grid), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
 }
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,

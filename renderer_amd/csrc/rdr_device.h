@@ -149,3 +149,15 @@ struct DFrame {
     const float* unorm_decode;  // 256 floats: i / 255
     uint32_t tex_white, tex_normal;
 };
+
+// Workgroups of a launch go to the 8 accelerator dies (XCDs, each with its own L2) round-robin by block index.
+// A kernel whose blocks are screen tiles maps block b to tile (b mod 8) * (grid / 8) + b / 8, so that each die works
+// through one contiguous eighth of the tile order and its L2 holds only that part of the shadow maps and textures.
+// The grid is rounded up to a multiple of 8; blocks whose tile is past the end return at once.
+#define RDR_XCDS 8u
+#define RDR_XCD_GRID(tiles) ((((tiles) + RDR_XCDS - 1u) / RDR_XCDS) * RDR_XCDS)
+#ifndef RDR_NO_XCD_MAP
+#define RDR_XCD_TILE(block, grid) (((block) % RDR_XCDS) * ((grid) / RDR_XCDS) + (block) / RDR_XCDS)
+#else
+#define RDR_XCD_TILE(block, grid) (block)  // timing experiments
+#endif
