@@ -212,6 +212,9 @@ typedef struct rdr_frame_stats {
     float avg_log_luminance;
     float ms_shade_kernel;        /* the opaque+sky shading kernel alone */
     float ms_raster_kernel;       /* the tile raster kernel(s) of the main batch alone */
+    uint64_t chunks_culled;       /* 64-triangle chunks whose bounding box the GPU culling pre-pass found outside a
+                                   * view (their triangles skip set-up); 0 from the CPU checker, which has no such
+                                   * pre-pass. The reference culls whole primitives only (VulkanRenderer.cpp:929-943). */
 } rdr_frame_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -29,7 +29,8 @@ int launch_radix_sort(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint3
 
 // kernels_raster.hip
 void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const uint32_t* draw_first, uint32_t n_draws, uint32_t n_inst,
-                  const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned);
+                  const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned,
+                  const uint32_t* chunk_first, uint32_t n_chunks, const void* chunk_bb, uint8_t* chunk_flags);
 void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const uint32_t* pair_offset, uint32_t n_inst, uint32_t n_pairs,
                  uint32_t* keys, uint32_t* vals);
 void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles,

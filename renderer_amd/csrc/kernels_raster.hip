@@ -4,6 +4,9 @@
 // Renderer/VulkanRendererShadow.cpp:72-118 shadow passes; vertex stage:
 // Renderer/shaders/shadowmap.vert:10-12, basic.vert:37).
 //
+//   k_chunk_cull  one thread per chunk of RDR_CHUNK_TRIS consecutive triangles of a
+//             draw: bounding box of the chunk against the view's clip planes
+//             -> one flag per chunk; set-up skips the triangles of culled chunks
 //   k_setup   one thread per triangle instance: transform, clip to a polygon
 //             (near, far, +-16384 px guard band), snap to 1/256 px, facing +
 //             cull, pixel/tile bounding box, depth plane   -> DTriRec
@@ -161,11 +164,81 @@ RDR_DEV uint32_t finish_record(const int32_t* X, const int32_t* Y, int n_in, con
     return (uint32_t)((ix1 / RDR_TILE - ix0 / RDR_TILE + 1) * (iy1 / RDR_TILE - iy0 / RDR_TILE + 1));
 }
 
+// GPU-side culling below the granularity of a draw. The reference culls whole primitives against the frustum on the
+// host (VulkanRenderer.cpp:929-943) and leaves the rest to the fixed-function clipper; here a pre-pass tests the
+// bounding box of every chunk of RDR_CHUNK_TRIS consecutive triangles, so that a ten-million-triangle primitive seen
+// through a shadow cascade that covers a corner of it costs set-up work only for that corner.
+//
+// A chunk is culled only if set-up would drop every triangle in it anyway, so nothing downstream changes. Two ways:
+//  * all of the box lies outside one of set-up's six clip planes (near, far, guard band): each of its triangles has
+//    its three vertices outside that plane;
+//  * all of the box lies in front of the eye (w > 0) and more than two pixels outside one side of the viewport: a
+//    polygon clipped from such a triangle keeps w > 0 and stays beyond that side, so its pixel box is empty.
+// With the same float matrix as coefficients a plane distance is a linear function of the position, so over the box
+// it is largest at a corner; the float evaluation at a vertex differs from the exact value by a few ulp of the sum
+// of the absolute values of its terms (A below, taken at the largest coordinates of the box), and the tests leave a
+// margin of 2^-16 A, hundreds of times that.
+__global__ void __launch_bounds__(256) k_chunk_cull(const DView* __restrict__ views, const DDraw* __restrict__ draws,
+                                                    const uint32_t* __restrict__ chunk_first, uint32_t n_draws, uint32_t n_chunks,
+                                                    const DPrim* __restrict__ prims, const float4* __restrict__ chunk_bb,
+                                                    uint8_t* __restrict__ flags, uint32_t* __restrict__ n_binned) {
+    const uint32_t ci = blockIdx.x * 256u + threadIdx.x;
+    const bool valid = ci < n_chunks;  // lanes past the end stay for the wave-wide count at the bottom
+    const uint32_t di = find_draw(chunk_first, n_draws, valid ? ci : 0u);
+    const DDraw& d = draws[di];
+    const DPrim& pr = prims[d.prim];
+    uint8_t culled = 0;
+    if (valid && pr.first_chunk != RDR_NO_CHUNKS) {
+        const DView& vw = views[d.view];
+        const float kx = 32768.0f / (float)vw.w, ky = 32768.0f / (float)vw.h;
+        const size_t at = 2 * ((size_t)pr.first_chunk + (ci - chunk_first[di]));
+        const float4 lo = chunk_bb[at], hi = chunk_bb[at + 1];
+        const float mx = fmaxf(fabsf(lo.x), fabsf(hi.x)), my = fmaxf(fabsf(lo.y), fabsf(hi.y)), mz = fmaxf(fabsf(lo.z), fabsf(hi.z));
+        const float* m = d.mvp;
+        float A[4];  // bound on the sum of absolute terms of clip x, y, z, w over the box
+#pragma unroll
+        for (int r = 0; r < 4; r++) A[r] = fabsf(m[r]) * mx + fabsf(m[4 + r]) * my + fabsf(m[8 + r]) * mz + fabsf(m[12 + r]);
+        const float eps = 1.52587890625e-05f;  // 2^-16
+        const float vx = 1.0f + 4.0f / (float)vw.w, vy = 1.0f + 4.0f / (float)vw.h;  // viewport sides, two pixels out
+        // planes 0..5 as in plane_dist; 6..9 the viewport's -x, +x, -y, +y sides
+        const float slack[10] = {eps * A[2], eps * (A[3] + A[2]), eps * (kx * A[3] + A[0]), eps * (kx * A[3] + A[0]), eps * (ky * A[3] + A[1]),
+                                 eps * (ky * A[3] + A[1]), eps * (vx * A[3] + A[0]), eps * (vx * A[3] + A[0]), eps * (vy * A[3] + A[1]),
+                                 eps * (vy * A[3] + A[1])};
+        uint32_t all_outside = 1023u;
+        bool finite = true, in_front = true;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const F4 q = xform_point(m, (k & 1) ? hi.x : lo.x, (k & 2) ? hi.y : lo.y, (k & 4) ? hi.z : lo.z);
+            const ClipV cv = {q.x, q.y, q.z, q.w};
+            finite = finite && isfinite(q.x) && isfinite(q.y) && isfinite(q.z) && isfinite(q.w);
+            in_front = in_front && q.w - eps * A[3] > 0.0f;
+            float dist[10];
+#pragma unroll
+            for (int plane = 0; plane < 6; plane++) dist[plane] = plane_dist(cv, plane, kx, ky);
+            dist[6] = fmaf(vx, q.w, q.x); dist[7] = fmaf(vx, q.w, -q.x); dist[8] = fmaf(vy, q.w, q.y); dist[9] = fmaf(vy, q.w, -q.y);
+#pragma unroll
+            for (int plane = 0; plane < 10; plane++)
+                if (!(dist[plane] + slack[plane] < 0.0f)) all_outside &= ~(1u << plane);
+        }
+        bool ok = finite;
+#pragma unroll
+        for (int plane = 0; plane < 10; plane++) ok = ok && isfinite(slack[plane]);
+        if (!in_front) all_outside &= 63u;
+        culled = (ok && all_outside) ? 1 : 0;
+    }
+    if (valid) flags[ci] = culled;
+    // statistic: culled chunks, summed per wave into word 4 of the spread counters (see k_setup)
+    const unsigned long long m = __ballot(culled != 0);
+    if (m && (threadIdx.x & 63u) == 0u)
+        atomicAdd(n_binned + (((blockIdx.x << 2) | (threadIdx.x >> 6)) & (RDR_BINNED_SLOTS - 1u)) * 32u + 4u, (uint32_t)__popcll(m));
+}
+
 __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, const DDraw* __restrict__ draws,
                                                const uint32_t* __restrict__ draw_first, uint32_t n_draws, uint32_t n_inst,
                                                const DPrim* __restrict__ prims, const float4* __restrict__ pos,
                                                const uint32_t* __restrict__ idx, DTriRec* __restrict__ recs,
-                                               uint32_t* __restrict__ pair_count, uint32_t* __restrict__ n_binned) {
+                                               uint32_t* __restrict__ pair_count, uint32_t* __restrict__ n_binned,
+                                               const uint32_t* __restrict__ chunk_first, const uint8_t* __restrict__ chunk_culled) {
     const uint32_t inst = blockIdx.x * 256u + threadIdx.x;
     const bool valid = inst < n_inst;  // lanes past the end stay for the wave-wide sums at the bottom
     uint32_t count = 0;  // records of dropped triangles are never read (they own no pair) and are left unwritten
@@ -178,6 +251,7 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
         const DView& vw = views[d.view];
         const DPrim& pr = prims[d.prim];
         const uint32_t tri = inst - d.first_instance;
+        if (chunk_culled[chunk_first[di] + tri / RDR_CHUNK_TRIS]) break;  // every triangle of the chunk lies outside one clip plane
         DTriRec& rec = recs[inst];
         blended_view = vw.load == 2u;
         const uint32_t* ip = idx + pr.first_index + 3u * tri;
@@ -589,10 +663,13 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
 }  // namespace
 
 void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const uint32_t* draw_first, uint32_t n_draws, uint32_t n_inst,
-                  const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned) {
+                  const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned,
+                  const uint32_t* chunk_first, uint32_t n_chunks, const void* chunk_bb, uint8_t* chunk_flags) {
     if (!n_inst) return;
+    hipLaunchKernelGGL(k_chunk_cull, dim3((n_chunks + 255) / 256), dim3(256), 0, s, views, draws, chunk_first, n_draws, n_chunks, prims,
+                       (const float4*)chunk_bb, chunk_flags, n_binned);
     hipLaunchKernelGGL(k_setup, dim3((n_inst + 255) / 256), dim3(256), 0, s, views, draws, draw_first, n_draws, n_inst, prims,
-                       (const float4*)pos, idx, recs, pair_count, n_binned);
+                       (const float4*)pos, idx, recs, pair_count, n_binned, chunk_first, chunk_flags);
 }
 void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const uint32_t* pair_offset, uint32_t n_inst, uint32_t n_pairs,
                  uint32_t* keys, uint32_t* vals) {

@@ -382,9 +382,12 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 }
 
 #define SHADE_NO_FRAGMENT 0xFFu
-#ifndef RDR_XCD_SQ_LOG2
-#define RDR_XCD_SQ_LOG2 3
-#endif
+// Workgroups of a launch go to the 8 dies (XCDs, each with its own L2) round-robin by block index. The opaque pass
+// walks the screen in squares of 2^RDR_SHADE_SQ_LOG2 tiles a side and deals the squares to the dies in turn: the
+// blocks a die has in flight then lie next to each other on the screen and share shadow-map and texture lines in its
+// L2, while every die still gets an even mix of cheap (sky) and expensive regions. The grid is padded to whole squares
+// and to a multiple of 8 squares; blocks of tiles outside the screen return at once.
+#define RDR_SHADE_SQ_LOG2 3u
 
 // Opaque draws + skybox. S == 1: writes hdr. S == 4: resolves straight into
 // hdr, except in tiles whose blended-pass triangle list is not empty
@@ -407,17 +410,10 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
     const DFrame& fr = *frp;
     lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
     const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
-    int tx, ty;
-    {
-#ifndef RDR_NO_XCD_MAP
-        // 8x8-tile squares, dealt round-robin to the dies: block b belongs to die b % 8 and is its (b / 8)-th block
-        const uint32_t Q = RDR_XCD_SQ_LOG2, side = 1u << Q;
-        const uint32_t k = blockIdx.x >> 3, sq = (k >> (2u * Q)) * 8u + (blockIdx.x & 7u), in = k & (side * side - 1u), sq_x = (tiles_x + side - 1u) >> Q;
-        tx = (int)((sq % sq_x) * side + (in & (side - 1u))); ty = (int)((sq / sq_x) * side + (in >> Q));
-#else
-        tx = (int)(blockIdx.x % tiles_x); ty = (int)(blockIdx.x / tiles_x);
-#endif
-    }
+    // block b belongs to die b % 8 and is that die's (b / 8)-th block
+    const uint32_t Q = RDR_SHADE_SQ_LOG2, side = 1u << Q;
+    const uint32_t nth = blockIdx.x >> 3, sq = (nth >> (2u * Q)) * 8u + (blockIdx.x & 7u), in_sq = nth & (side * side - 1u), sq_x = (tiles_x + side - 1u) >> Q;
+    const int tx = (int)((sq % sq_x) * side + (in_sq & (side - 1u))), ty = (int)((sq / sq_x) * side + (in_sq >> Q));
     if ((uint32_t)tx >= tiles_x || (uint32_t)ty * tiles_x + (uint32_t)tx >= n_tiles) return;
     const uint32_t tile = (uint32_t)ty * tiles_x + (uint32_t)tx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -722,12 +718,8 @@ void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, con
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H) {
     const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
-#ifndef RDR_NO_XCD_MAP
-    const uint32_t side = 1u << RDR_XCD_SQ_LOG2;
+    const uint32_t side = 1u << RDR_SHADE_SQ_LOG2;
     const uint32_t grid = ((((W + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) * (((H + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) + 7u) / 8u * 8u * side * side;
-#else
-    const uint32_t grid = tiles;
-#endif
     if (samples == 1)
         hipLaunchKernelGGL(k_shade_opaque<1>, dim3(grid), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
     else

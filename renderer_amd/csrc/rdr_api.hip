@@ -125,6 +125,7 @@ struct rdr_ctx {
     // scene, device side
     DevBuf d_pos, d_attr, d_idx, d_prims, d_textures, d_lights, d_tables, d_trig;
     DevBuf d_rest_pos, d_rest_attr, d_skin_joints, d_skin_weights, d_skin_dst_pal, d_palette;
+    DevBuf d_chunk_bb;  // bounding boxes of the chunks of RDR_CHUNK_TRIS triangles (GPU-side culling), see upload_scene
     PinBuf h_palette;
     DevBuf d_env, d_irradiance, d_prefiltered, d_lut;
     DCube env{}, irradiance{}, prefiltered{};
@@ -136,6 +137,7 @@ struct rdr_ctx {
     bool have_frame = false, have_post = false;
 
     // raster scratch
+    DevBuf d_chunk_first, d_chunk_flags;
     DevBuf d_views, d_draws, d_draw_first, d_first_tri, d_recs, d_pair_count, d_scan, d_hist, d_tile_start, d_tile_end, d_counters, d_binned, d_frame;
     DevBuf d_keys[2], d_vals[2];
     DevBuf d_shade_tris;  // DShadeTri per triangle of the view being shaded
@@ -287,12 +289,32 @@ int upload_scene(rdr_ctx* c) {
             HIP_TRY(hipMemcpy(c->d_attr.p, c->h_attr.data(), c->h_attr.size() * sizeof(DVertexAttr), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(c->d_idx.p, c->h_idx.data(), c->h_idx.size() * 4, hipMemcpyHostToDevice));
         }
+        // boxes of every RDR_CHUNK_TRIS consecutive triangles of the rigid primitives, in model space (k_chunk_cull)
+        std::vector<float> chunk_bb;
+        std::vector<uint32_t> first_chunk(c->prims.size(), RDR_NO_CHUNKS);
+        for (size_t i = 0; i < c->prims.size(); i++) {
+            const HostPrim& p = c->prims[i];
+            if (p.skinned) continue;
+            first_chunk[i] = (uint32_t)(chunk_bb.size() / 8);
+            for (uint32_t t0 = 0; t0 < p.tri_count; t0 += RDR_CHUNK_TRIS) {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                const uint32_t t1 = std::min(p.tri_count, t0 + RDR_CHUNK_TRIS);
+                for (size_t k = (size_t)p.first_index + 3u * t0; k < (size_t)p.first_index + 3u * t1; k++) {
+                    const float* v = &c->h_pos[((size_t)p.first_vertex + c->h_idx[k]) * 4];
+                    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], v[a]); hi[a] = std::max(hi[a], v[a]); }
+                }
+                const float box[8] = {lo[0], lo[1], lo[2], 0.0f, hi[0], hi[1], hi[2], 0.0f};
+                chunk_bb.insert(chunk_bb.end(), box, box + 8);
+            }
+        }
+        HIP_TRY(c->d_chunk_bb.ensure(std::max<size_t>(chunk_bb.size() * 4, 32)));
+        if (!chunk_bb.empty()) HIP_TRY(hipMemcpy(c->d_chunk_bb.p, chunk_bb.data(), chunk_bb.size() * 4, hipMemcpyHostToDevice));
         std::vector<DPrim> dp(std::max<size_t>(c->prims.size(), 1));
         for (size_t i = 0; i < c->prims.size(); i++) {
             const HostPrim& p = c->prims[i];
             DPrim& d = dp[i];
             memset(&d, 0, sizeof d);
-            d.first_vertex = p.first_vertex; d.first_index = p.first_index; d.tri_count = p.tri_count;
+            d.first_vertex = p.first_vertex; d.first_index = p.first_index; d.tri_count = p.tri_count; d.first_chunk = first_chunk[i];
             memcpy(d.mat.base_color, p.mat.base_color_factor, 16);
             memcpy(d.mat.emissive, p.mat.emissive_factor, 16);
             d.mat.metallic = p.mat.metallic_factor; d.mat.roughness = p.mat.roughness_factor; d.mat.ao = p.mat.ao_factor;
@@ -389,34 +411,42 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
         n_tiles += v.tiles_x * v.tiles_y;
     }
     const uint32_t n_draws = (uint32_t)b.draws.size();
-    std::vector<uint32_t> draw_first(n_draws + 1, 0), first_tri(n_draws + 1, 0);
+    std::vector<uint32_t> draw_first(n_draws + 1, 0), first_tri(n_draws + 1, 0), chunk_first(n_draws + 1, 0);
     uint64_t inst64 = 0;
+    uint32_t n_chunks = 0;  // one flag per RDR_CHUNK_TRIS triangle instances of a draw: at most 2^26 + one per draw
     for (uint32_t i = 0; i < n_draws; i++) {
         b.draws[i].first_instance = (uint32_t)inst64;
         draw_first[i] = (uint32_t)inst64;
         first_tri[i] = b.draws[i].first_tri_id;
+        chunk_first[i] = n_chunks;
         inst64 += c->prims[b.draws[i].prim].tri_count;
+        n_chunks += (c->prims[b.draws[i].prim].tri_count + RDR_CHUNK_TRIS - 1u) / RDR_CHUNK_TRIS;
     }
+    chunk_first[n_draws] = n_chunks;
     if (inst64 >= 0xFFFFFFF0ull) return fail(c, RDR_ERR_CAPACITY, "more than 2^32 triangle instances in one batch");
     const uint32_t n_inst = (uint32_t)inst64;
     c->batch_instances = n_inst;
     draw_first[n_draws] = n_inst;
     // stage the tables in pinned memory and upload
     const size_t sz_views = b.views.size() * sizeof(DView), sz_draws = std::max<size_t>(n_draws, 1) * sizeof(DDraw), sz_first = (n_draws + 1) * 4;
-    HIP_TRY(c->h_stage.ensure(sz_views + sz_draws + 2 * sz_first + 64));
+    HIP_TRY(c->h_stage.ensure(sz_views + sz_draws + 3 * sz_first + 64));
     uint8_t* st = c->h_stage.as<uint8_t>();
     memcpy(st, b.views.data(), sz_views);
     if (n_draws) memcpy(st + sz_views, b.draws.data(), n_draws * sizeof(DDraw));
     memcpy(st + sz_views + sz_draws, draw_first.data(), sz_first);
     memcpy(st + sz_views + sz_draws + sz_first, first_tri.data(), sz_first);
+    memcpy(st + sz_views + sz_draws + 2 * sz_first, chunk_first.data(), sz_first);
     HIP_TRY(c->d_views.ensure(sz_views));
     HIP_TRY(c->d_draws.ensure(sz_draws));
     HIP_TRY(c->d_draw_first.ensure(sz_first));
     HIP_TRY(c->d_first_tri.ensure(sz_first));
+    HIP_TRY(c->d_chunk_first.ensure(sz_first));
+    HIP_TRY(c->d_chunk_flags.ensure(std::max<size_t>(n_chunks, 16)));
     HIP_TRY(hipMemcpyAsync(c->d_views.p, st, sz_views, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_draws.p, st + sz_views, sz_draws, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_draw_first.p, st + sz_views + sz_draws, sz_first, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_first_tri.p, st + sz_views + sz_draws + sz_first, sz_first, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_chunk_first.p, st + sz_views + sz_draws + 2 * sz_first, sz_first, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_recs.ensure(std::max<size_t>(n_inst, 1) * sizeof(DTriRec)));
     HIP_TRY(c->d_pair_count.ensure(std::max<size_t>(n_inst, 1) * 4));
     HIP_TRY(c->d_tile_start.ensure(std::max<size_t>(n_tiles, 1) * 4));
@@ -425,7 +455,7 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     uint32_t* counters = c->d_counters.as<uint32_t>();  // [0] pair total, [2] scratch total, [3] valid pairs
     launch_setup(c->stream, c->d_views.as<DView>(), c->d_draws.as<DDraw>(), c->d_draw_first.as<uint32_t>(), n_draws, n_inst,
                  c->d_prims.as<DPrim>(), c->d_pos.p, c->d_idx.as<uint32_t>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(),
-                 c->d_binned.as<uint32_t>());
+                 c->d_binned.as<uint32_t>(), c->d_chunk_first.as<uint32_t>(), n_chunks, c->d_chunk_bb.p, c->d_chunk_flags.as<uint8_t>());
     launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
     HIP_TRY(c->h_read.ensure(64 + RDR_BINNED_SLOTS * 128));
     HIP_TRY(hipMemcpyAsync(c->h_read.p, counters, 4, hipMemcpyDeviceToHost, c->stream));
@@ -749,7 +779,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_views, &c->d_draws,
                       &c->d_draw_first, &c->d_first_tri, &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start, &c->d_tile_end,
                       &c->d_counters, &c->d_binned, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_frag_used, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
-                      &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
+                      &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_first, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
@@ -1338,9 +1368,13 @@ int rdr_synchronize(rdr_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->have_frame && c->h_read.p) {
         memcpy(&c->last_avg_log_lum, c->h_read.as<uint8_t>() + 16, 4);
-        uint32_t binned = 0;
-        for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) binned += c->h_read.as<uint32_t>()[16 + k * 32];
+        uint32_t binned = 0, chunks_culled = 0;
+        for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
+            binned += c->h_read.as<uint32_t>()[16 + k * 32];
+            chunks_culled += c->h_read.as<uint32_t>()[16 + k * 32 + 4];
+        }
         c->stats.triangles_binned = binned;
+        c->stats.chunks_culled = chunks_culled;
         c->stats.avg_log_luminance = c->last_avg_log_lum;
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_geometry = ms;

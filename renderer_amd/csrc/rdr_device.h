@@ -9,6 +9,8 @@
 #define RDR_MAX_TEX_LEVELS 16
 #define RDR_PAIR_INVALID 0xFFFFFFFFu
 #define RDR_BINNED_SLOTS 64u     // counters (128 bytes apart) the binned-triangle statistic is spread over
+#define RDR_CHUNK_TRIS 64u       // consecutive triangles of a primitive that share one bounding box for GPU-side culling
+#define RDR_NO_CHUNKS 0xFFFFFFFFu  // DPrim::first_chunk of a primitive without chunk boxes (skinned: its vertices move)
 
 // Material block of one primitive (PBRInfo + AlphaInfo of the reference,
 // read by pbr.frag:21-37) plus its five texture slots.
@@ -27,7 +29,7 @@ struct DPrim {
     uint32_t first_vertex;  // into pos[] / attr[]
     uint32_t first_index;   // into idx[]
     uint32_t tri_count;
-    uint32_t _pad;
+    uint32_t first_chunk;   // into the chunk boxes (two float4 each: min, max in model space), or RDR_NO_CHUNKS
     DMaterial mat;
 };
 
@@ -149,15 +151,3 @@ struct DFrame {
     const float* unorm_decode;  // 256 floats: i / 255
     uint32_t tex_white, tex_normal;
 };
-
-// Workgroups of a launch go to the 8 accelerator dies (XCDs, each with its own L2) round-robin by block index.
-// A kernel whose blocks are screen tiles maps block b to tile (b mod 8) * (grid / 8) + b / 8, so that each die works
-// through one contiguous eighth of the tile order and its L2 holds only that part of the shadow maps and textures.
-// The grid is rounded up to a multiple of 8; blocks whose tile is past the end return at once.
-#define RDR_XCDS 8u
-#define RDR_XCD_GRID(tiles) ((((tiles) + RDR_XCDS - 1u) / RDR_XCDS) * RDR_XCDS)
-#ifndef RDR_NO_XCD_MAP
-#define RDR_XCD_TILE(block, grid) (((block) % RDR_XCDS) * ((grid) / RDR_XCDS) + (block) / RDR_XCDS)
-#else
-#define RDR_XCD_TILE(block, grid) (block)  // timing experiments
-#endif

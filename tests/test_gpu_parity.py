@@ -139,3 +139,39 @@ def test_degenerate_scenes(orc_capi, hip_capi, msaa):
     so, sh = ro.frame_stats(), rh.frame_stats()
     assert so.triangles_binned == sh.triangles_binned == 0
     ro.close(); rh.close()
+
+
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_chunk_culling_changes_nothing(orc_capi, hip_capi, msaa):
+    """A finely tessellated floor far larger than the view, seen from close above it through a small frame whose size
+    is not a multiple of the tile: most 64-triangle chunks lie beside or behind the frustum and the GPU pre-pass culls
+    them (the statistic says so), some straddle the near plane and the sides of the viewport. The CPU checker has no
+    such pre-pass; depth, visibility, the cascades and the number of triangles that reach the tile lists must not
+    notice."""
+    W, H = 71, 53
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, **hp.small_settings(msaa))
+    for r in (ro, rh):
+        tex = scenes.material_textures(r, 16, 3)
+        floor = scenes.plane(80.0, 80.0, 96, 96, uv_scale=16.0)
+        r.add_mesh([scenes.upload_primitive(r, floor, scenes.make_material(tex))])
+        r.add_mesh([scenes.upload_primitive(r, scenes.box(1.0, 2.0, 1.0, 6).transformed(scenes.translation(0.5, 1.0, -1.0)),
+                                            scenes.make_material(tex), scenes.B.UINT16)])
+        r.set_brdf_lut(scenes.brdf_lut(16, 16))
+        r.set_environment_map(scenes.sky_faces(16))
+        r.set_lights([((2.0, 3.0, 1.0), (30.0, 30.0, 30.0), True)], scenes.default_directional_light())
+    for position, euler in (((0.3, 0.6, 2.5), (-0.15, 0.2, 0.0)), ((-30.0, 0.4, 35.0), (-0.05, -0.7, 0.0)), ((0.0, 25.0, 0.0), (-1.5, 0.0, 0.0))):
+        for r in (ro, rh):
+            r.set_camera(position=position, euler=euler)
+        out_o, _ = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        out_h, _ = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        assert np.array_equal(ro.read_depth(), rh.read_depth())
+        assert np.array_equal(ro.read_visibility(), rh.read_visibility())
+        for i in range(4):
+            assert np.array_equal(ro.read_directional_shadow(i), rh.read_directional_shadow(i)), f"cascade {i}"
+        for face in range(6):
+            assert np.array_equal(ro.read_point_shadow(0, face), rh.read_point_shadow(0, face)), f"point face {face}"
+        so, sh = ro.frame_stats(), rh.frame_stats()
+        assert (so.triangle_instances, so.triangles_binned) == (sh.triangle_instances, sh.triangles_binned)
+        assert so.chunks_culled == 0 and sh.chunks_culled > 0
+        hp.assert_image_close(out_o, out_h)
+    assert (rh.read_depth() < 1.0).any()
