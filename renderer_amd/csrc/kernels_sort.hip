@@ -14,6 +14,7 @@
 #define SCAN_BLOCK 256
 #define SCAN_ITEMS 16
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
+#define SCAN_RAW_MAX_TILES 2048u  // up to here every scan block sums the tile totals before it itself (8 M elements)
 #define SORT_ROUNDS 16
 #define SORT_CHUNK (64 * SORT_ROUNDS)
 #define SORT_MAX_BINS 512
@@ -76,10 +77,24 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(uint32_t* __restrict__
     if (threadIdx.x == 0) out_total[0] = carry;
 }
 
+// RAW: block_sums holds the tile totals as k_scan_reduce left them, and every block adds up the totals before its own
+// itself (block 0 also writes the grand total). With a few hundred tiles that is cheaper than a single-block kernel in
+// between, whose launch and drain cost more than its work.
+template <bool RAW>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ block_sums,
-                                                           uint32_t* __restrict__ out) {
+                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ out_total) {
     __shared__ uint32_t ws[SCAN_BLOCK / 64];
     const uint32_t base = blockIdx.x * SCAN_TILE;
+    uint32_t before = 0;
+    if (RAW) {
+        const uint32_t upto = blockIdx.x == 0 ? gridDim.x : blockIdx.x;  // block 0 has nothing before it: it sums everything
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < upto; i += SCAN_BLOCK) part += block_sums[i];
+        uint32_t sum;
+        block_exclusive_scan(part, ws, sum);
+        if (blockIdx.x == 0) { if (threadIdx.x == 0) out_total[0] = sum; }
+        else before = sum;
+    } else before = block_sums[blockIdx.x];
     // thread t owns SCAN_ITEMS consecutive elements so that the running sum stays in registers
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
@@ -90,7 +105,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __res
         s += v[k];
     }
     uint32_t total;
-    uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan(s, ws, total);
+    uint32_t run = before + block_exclusive_scan(s, ws, total);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const uint32_t i = base + threadIdx.x * SCAN_ITEMS + k;
@@ -166,8 +181,12 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
     if (n == 0) { (void)hipMemsetAsync(d_total, 0, 4, s); return; }
     const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n, scratch);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scratch, nb, d_total);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n, (const uint32_t*)scratch, out);
+    if (nb <= SCAN_RAW_MAX_TILES) {
+        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n, (const uint32_t*)scratch, out, d_total);
+    } else {
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scratch, nb, d_total);
+        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n, (const uint32_t*)scratch, out, d_total);
+    }
 }
 
 uint32_t sort_chunks(uint32_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }
