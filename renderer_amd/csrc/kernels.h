@@ -33,8 +33,7 @@ void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const u
                   const uint32_t* chunk_first, uint32_t n_chunks, const void* chunk_bb, uint8_t* chunk_flags);
 void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const uint32_t* pair_offset, uint32_t n_inst, uint32_t n_pairs,
                  uint32_t* keys, uint32_t* vals);
-void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles,
-                   uint32_t* n_valid);
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_ranges, uint32_t n_tiles);
 // tiles [first_tile, end_tile) hold the views of one sample count, the first of which is view first_view
 struct RasterRange { uint32_t first_tile, end_tile, first_view; };
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
@@ -45,7 +44,8 @@ void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, con
                         const uint32_t* pair_offset, uint32_t n_after, const uint32_t* pair_total, DShadeTri* out);
 void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H);
-// blended pass: fragment list slots are handed out in runs of RDR_FRAG_RUN; `capacity` slots exist (see blend_capacity)
+// blended pass: fragment list slots are handed out in runs of RDR_FRAG_RUN; `capacity` slots exist (see blend_capacity);
+// *frag_used counts the slots handed out and must be zero when launch_raster_blend is called
 #define RDR_FRAG_RUN 128u
 #define RDR_BLEND_SHADE_BLOCKS 2048u
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,

@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) k_emit(const DView* __restrict__ views, c
 }
 
 __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ keys, uint32_t n_pairs, uint32_t* __restrict__ tile_start,
-                                                uint32_t* __restrict__ tile_end, uint32_t* __restrict__ n_valid) {
+                                                uint32_t* __restrict__ tile_end) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t k = keys[p];
@@ -408,9 +408,8 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
     if (k != prev || p == 0) {
         if (k != RDR_PAIR_INVALID) tile_start[k] = p;
         if (p && prev != RDR_PAIR_INVALID) tile_end[prev] = p;
-        if (k == RDR_PAIR_INVALID) n_valid[0] = p;
     }
-    if (p == n_pairs - 1 && k != RDR_PAIR_INVALID) { tile_end[k] = n_pairs; n_valid[0] = n_pairs; }
+    if (p == n_pairs - 1 && k != RDR_PAIR_INVALID) tile_end[k] = n_pairs;
 }
 
 // threads per tile and records staged per pass: single-sampled views (shadow maps), 4x multisampled view
@@ -462,7 +461,10 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
     const uint32_t local_tile = tile - vw.tile_base;
     if (local_tile >= vw.tiles_x * vw.tiles_y) return;
     const uint32_t begin = tile_start[tile], end = tile_end[tile];
-    if (vw.load && begin >= end) return;  // nothing to add to what the target holds
+    // load == 1 with the initial depth in another buffer (a point-light face that starts from its cached static map):
+    // the tile is carried over here, so no separate copy of the map is needed
+    const bool carry = vw.load && vw.init != vw.depth;
+    if (vw.load && !carry && begin >= end) return;  // nothing to add to what the target holds
     const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
     const int tid = (int)threadIdx.x;
     const size_t plane_px = (size_t)vw.w * vw.h;
@@ -474,7 +476,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
                 const size_t at = (size_t)cy * vw.w + cx;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    vw.depth[s * plane_px + at] = 1.0f;
+                    vw.depth[s * plane_px + at] = carry ? vw.init[s * plane_px + at] : 1.0f;
                     if (vw.vis) vw.vis[s * plane_px + at] = RDR_PAIR_INVALID;
                 }
             }
@@ -489,7 +491,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
         const bool in_view = px < (int)vw.w && py < (int)vw.h;
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            zi[q][s] = __float_as_uint((vw.load && in_view) ? vw.depth[s * plane_px + (size_t)py * vw.w + px] : 1.0f);
+            zi[q][s] = __float_as_uint((vw.load && in_view) ? vw.init[s * plane_px + (size_t)py * vw.w + px] : 1.0f);
             lds_key[s * 256 + pix] = (unsigned long long)zi[q][s] << 32;
         }
     }
@@ -648,7 +650,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
             key[s] = lds_key[s * 256 + pix];
             changed = changed || key[s] != ((unsigned long long)zi[q][s] << 32);
         }
-        if (!vw.load || changed) {
+        if (!vw.load || carry || changed) {
 #pragma unroll
             for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
         }
@@ -676,13 +678,11 @@ void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const u
     if (!n_pairs) return;
     hipLaunchKernelGGL(k_emit, dim3((n_pairs + 255) / 256), dim3(256), 0, s, views, recs, pair_offset, n_inst, n_pairs, keys, vals);
 }
-void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_start, uint32_t* tile_end, uint32_t n_tiles,
-                   uint32_t* n_valid) {
-    (void)hipMemsetAsync(tile_start, 0, (size_t)n_tiles * 4, s);
-    (void)hipMemsetAsync(tile_end, 0, (size_t)n_tiles * 4, s);
-    (void)hipMemsetAsync(n_valid, 0, 4, s);
+// `tile_ranges` = tile_start[n_tiles] followed by tile_end[n_tiles]: cleared with one fill
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_ranges, uint32_t n_tiles) {
+    (void)hipMemsetAsync(tile_ranges, 0, (size_t)n_tiles * 8, s);
     if (!n_pairs) return;
-    hipLaunchKernelGGL(k_ranges, dim3((n_pairs + 255) / 256), dim3(256), 0, s, keys, n_pairs, tile_start, tile_end, n_valid);
+    hipLaunchKernelGGL(k_ranges, dim3((n_pairs + 255) / 256), dim3(256), 0, s, keys, n_pairs, tile_ranges, tile_ranges + n_tiles);
 }
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
                    const uint32_t* tile_start, const uint32_t* tile_end, RasterRange s1, RasterRange s4) {

@@ -729,7 +729,6 @@ void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DVi
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
                          void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity) {
     if (!n_tiles) return;
-    (void)hipMemsetAsync(frag_used, 0, 4, s);
     if (samples == 1)
         hipLaunchKernelGGL(k_blend_collect<1>, dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
                            frag_used, capacity);

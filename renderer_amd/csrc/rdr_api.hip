@@ -24,6 +24,15 @@ using namespace rdr;
 
 namespace {
 
+// d_counters: 64 bytes of scalar counters, then the spread counters. h_read (pinned): [0, RDR_COUNTER_BYTES) is what the
+// end of a frame reads back (average luminance in word RDR_COUNTER_LUM, spread counters from byte 64), [RDR_READ_MID, +RDR_COUNTER_BYTES)
+// what a batch reads back between its pair scan and its sort.
+#define RDR_COUNTER_BYTES (64u + RDR_BINNED_SLOTS * 128u)
+#define RDR_COUNTER_LUM 4u  // word of the scalar counters that the luminance reduction writes its result to
+#define RDR_COUNTER_FRAGS 5u  // word the blended pass counts its fragment-list slots in (zero after the frame's fill)
+#define RDR_READ_MID RDR_COUNTER_BYTES
+#define RDR_READ_BYTES (2u * RDR_COUNTER_BYTES)
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -43,6 +52,14 @@ struct DevBuf {
         return hipSuccess;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// A typed window into somebody else's DevBuf: several small tables that are uploaded, cleared or read back together
+// live in one allocation, so that they move with one copy / one fill instead of one each (every small copy or fill is
+// its own command on the stream, a few microseconds the kernels behind it wait for).
+struct DevSpan {
+    void* p = nullptr;
     template <class T> T* as() const { return (T*)p; }
 };
 
@@ -123,7 +140,7 @@ struct rdr_ctx {
     mat4 csm_viewproj[4];
 
     // scene, device side
-    DevBuf d_pos, d_attr, d_idx, d_prims, d_textures, d_lights, d_tables, d_trig;
+    DevBuf d_pos, d_attr, d_idx, d_prims, d_textures, d_tables, d_trig;
     DevBuf d_rest_pos, d_rest_attr, d_skin_joints, d_skin_weights, d_skin_dst_pal, d_palette;
     DevBuf d_chunk_bb;  // bounding boxes of the chunks of RDR_CHUNK_TRIS triangles (GPU-side culling), see upload_scene
     PinBuf h_palette;
@@ -137,15 +154,23 @@ struct rdr_ctx {
     bool have_frame = false, have_post = false;
 
     // raster scratch
-    DevBuf d_chunk_first, d_chunk_flags;
-    DevBuf d_views, d_draws, d_draw_first, d_first_tri, d_recs, d_pair_count, d_scan, d_hist, d_tile_start, d_tile_end, d_counters, d_binned, d_frame;
+    DevBuf d_chunk_flags;
+    DevBuf d_batch_tables;  // views | draws | draw_first | first_tri | chunk_first of the batch being rasterised, one upload
+    DevSpan d_views, d_draws, d_draw_first, d_first_tri, d_chunk_first;
+    DevBuf d_recs, d_pair_count, d_scan, d_hist;
+    DevBuf d_tile_start;    // tile_start[n_tiles] | tile_end[n_tiles], one fill
+    DevSpan d_tile_end;
+    DevBuf d_counters;      // 64 bytes of scalar counters | RDR_BINNED_SLOTS x 128 bytes of spread counters, one fill, one read-back
+    DevSpan d_binned;
+    DevBuf d_frame;         // DFrame | point lights, one upload
+    DevSpan d_lights;
     DevBuf d_keys[2], d_vals[2];
     DevBuf d_shade_tris;  // DShadeTri per triangle of the view being shaded
     PinBuf h_stage, h_read;
     std::vector<DDraw> main_draws;  // opaque draws of the last frame (kept for read-backs)
     uint32_t batch_instances = 0;   // triangle instances of the last raster batch
     uint64_t blend_pairs = 0, blend_box_pixels = 0;  // of the last batch: (triangle, tile) pairs / box pixels of blended-view triangles
-    DevBuf d_frags, d_frag_col, d_frag_head, d_frag_used;
+    DevBuf d_frags, d_frag_col, d_frag_head;  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
 
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     rdr_frame_stats stats{};
@@ -428,46 +453,45 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     c->batch_instances = n_inst;
     draw_first[n_draws] = n_inst;
     // stage the tables in pinned memory and upload
-    const size_t sz_views = b.views.size() * sizeof(DView), sz_draws = std::max<size_t>(n_draws, 1) * sizeof(DDraw), sz_first = (n_draws + 1) * 4;
-    HIP_TRY(c->h_stage.ensure(sz_views + sz_draws + 3 * sz_first + 64));
+    auto round16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t sz_views = round16(b.views.size() * sizeof(DView)), sz_draws = round16(std::max<size_t>(n_draws, 1) * sizeof(DDraw)),
+                 sz_first = round16((n_draws + 1) * 4);
+    const size_t sz_tables = sz_views + sz_draws + 3 * sz_first;
+    HIP_TRY(c->h_stage.ensure(sz_tables + 64));
     uint8_t* st = c->h_stage.as<uint8_t>();
-    memcpy(st, b.views.data(), sz_views);
+    memcpy(st, b.views.data(), b.views.size() * sizeof(DView));
     if (n_draws) memcpy(st + sz_views, b.draws.data(), n_draws * sizeof(DDraw));
-    memcpy(st + sz_views + sz_draws, draw_first.data(), sz_first);
-    memcpy(st + sz_views + sz_draws + sz_first, first_tri.data(), sz_first);
-    memcpy(st + sz_views + sz_draws + 2 * sz_first, chunk_first.data(), sz_first);
-    HIP_TRY(c->d_views.ensure(sz_views));
-    HIP_TRY(c->d_draws.ensure(sz_draws));
-    HIP_TRY(c->d_draw_first.ensure(sz_first));
-    HIP_TRY(c->d_first_tri.ensure(sz_first));
-    HIP_TRY(c->d_chunk_first.ensure(sz_first));
+    memcpy(st + sz_views + sz_draws, draw_first.data(), (n_draws + 1) * 4);
+    memcpy(st + sz_views + sz_draws + sz_first, first_tri.data(), (n_draws + 1) * 4);
+    memcpy(st + sz_views + sz_draws + 2 * sz_first, chunk_first.data(), (n_draws + 1) * 4);
+    HIP_TRY(c->d_batch_tables.ensure(sz_tables));
+    uint8_t* dt = c->d_batch_tables.as<uint8_t>();
+    c->d_views.p = dt; c->d_draws.p = dt + sz_views; c->d_draw_first.p = dt + sz_views + sz_draws;
+    c->d_first_tri.p = dt + sz_views + sz_draws + sz_first; c->d_chunk_first.p = dt + sz_views + sz_draws + 2 * sz_first;
+    HIP_TRY(hipMemcpyAsync(dt, st, sz_tables, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_chunk_flags.ensure(std::max<size_t>(n_chunks, 16)));
-    HIP_TRY(hipMemcpyAsync(c->d_views.p, st, sz_views, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_draws.p, st + sz_views, sz_draws, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_draw_first.p, st + sz_views + sz_draws, sz_first, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_first_tri.p, st + sz_views + sz_draws + sz_first, sz_first, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_chunk_first.p, st + sz_views + sz_draws + 2 * sz_first, sz_first, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_recs.ensure(std::max<size_t>(n_inst, 1) * sizeof(DTriRec)));
     HIP_TRY(c->d_pair_count.ensure(std::max<size_t>(n_inst, 1) * 4));
-    HIP_TRY(c->d_tile_start.ensure(std::max<size_t>(n_tiles, 1) * 4));
-    HIP_TRY(c->d_tile_end.ensure(std::max<size_t>(n_tiles, 1) * 4));
+    HIP_TRY(c->d_tile_start.ensure(std::max<size_t>(n_tiles, 1) * 8));
+    c->d_tile_end.p = c->d_tile_start.as<uint32_t>() + n_tiles;
     HIP_TRY(c->d_scan.ensure((scan_scratch_words(n_inst) + 16) * 4));
-    uint32_t* counters = c->d_counters.as<uint32_t>();  // [0] pair total, [2] scratch total, [3] valid pairs
+    uint32_t* counters = c->d_counters.as<uint32_t>();  // [0] pair total, [2] scratch total
     launch_setup(c->stream, c->d_views.as<DView>(), c->d_draws.as<DDraw>(), c->d_draw_first.as<uint32_t>(), n_draws, n_inst,
                  c->d_prims.as<DPrim>(), c->d_pos.p, c->d_idx.as<uint32_t>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(),
                  c->d_binned.as<uint32_t>(), c->d_chunk_first.as<uint32_t>(), n_chunks, c->d_chunk_bb.p, c->d_chunk_flags.as<uint8_t>());
     launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
-    HIP_TRY(c->h_read.ensure(64 + RDR_BINNED_SLOTS * 128));
-    HIP_TRY(hipMemcpyAsync(c->h_read.p, counters, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 64, c->d_binned.p, RDR_BINNED_SLOTS * 128, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c->h_read.ensure(RDR_READ_BYTES));
+    // scalar counters and spread counters in one copy; it lands beside the block the end of the frame is read into
+    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + RDR_READ_MID, counters, RDR_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_pairs, c->stream));
     if (after_scan) RDR_TRY(after_scan());
     HIP_TRY(hipEventSynchronize(c->ev_pairs));
-    const uint32_t n_pairs = c->h_read.as<uint32_t>()[0];
+    const uint32_t* mid = (const uint32_t*)(c->h_read.as<uint8_t>() + RDR_READ_MID);
+    const uint32_t n_pairs = mid[0];
     // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
     c->blend_pairs = 0; c->blend_box_pixels = 0;
     for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
-        const uint32_t* slot = c->h_read.as<uint32_t>() + 16 + k * 32;
+        const uint32_t* slot = mid + 16 + k * 32;
         c->blend_pairs += slot[1];
         unsigned long long a; memcpy(&a, slot + 2, 8);
         c->blend_box_pixels += a;
@@ -485,7 +509,7 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     uint32_t* keys[2] = {c->d_keys[0].as<uint32_t>(), c->d_keys[1].as<uint32_t>()};
     uint32_t* vals[2] = {c->d_vals[0].as<uint32_t>(), c->d_vals[1].as<uint32_t>()};
     const int cur = launch_radix_sort(c->stream, keys, vals, n_pairs, key_bits, c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(), counters + 2);
-    launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, counters + 3);
+    launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), n_tiles);
     c->stats.triangle_instances += n_inst;
     c->stats.tile_pairs += n_pairs;
     c->stats.views += (uint32_t)b.views.size();
@@ -520,10 +544,10 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
     return RDR_OK;
 }
 
-DView make_view(float* depth, uint32_t* vis, uint32_t w, uint32_t h, uint32_t samples, uint32_t cull, uint32_t load) {
+DView make_view(float* depth, uint32_t* vis, uint32_t w, uint32_t h, uint32_t samples, uint32_t cull, uint32_t load, const float* init = nullptr) {
     DView v;
     memset(&v, 0, sizeof v);
-    v.depth = depth; v.vis = vis; v.w = w; v.h = h; v.samples = samples; v.cull = cull; v.load = load;
+    v.depth = depth; v.init = init ? init : depth; v.vis = vis; v.w = w; v.h = h; v.samples = samples; v.cull = cull; v.load = load;
     return v;
 }
 
@@ -595,7 +619,8 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
                                    hipMemcpyDeviceToDevice, c->stream));
         }
     }
-    // dynamic meshes on top of a copy of the static face
+    // dynamic meshes on top of the static face: the rasteriser starts every tile of such a face from the cached static
+    // map (DView::init) and writes the result to the map the shaders read, so the static map is never copied
     for (uint32_t i : slotted) {
         HostLight& l = c->lights[i];
         for (int j = 0; j < 6; j++) {
@@ -605,9 +630,8 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
             append_draws(c, dynamic_prims, vp, l.point, SORT_FRONT_TO_BACK, (uint32_t)dynamic_batch.views.size(), dynamic_batch.draws);
             if (c->settings.dynamic_shadows_enabled && dynamic_batch.draws.size() > n_before) {
                 const size_t off = ((size_t)l.slot * 6 + j) * face_px;
-                HIP_TRY(hipMemcpyAsync(c->d_point_shadow.as<float>() + off, c->d_point_static.as<float>() + off, face_px * 4,
-                                       hipMemcpyDeviceToDevice, c->stream));
-                dynamic_batch.views.push_back(make_view(c->d_point_shadow.as<float>() + off, nullptr, res, res, 1, 1, 1));
+                dynamic_batch.views.push_back(make_view(c->d_point_shadow.as<float>() + off, nullptr, res, res, 1, 1, 1,
+                                                        c->d_point_static.as<float>() + off));
             } else {
                 dynamic_batch.draws.resize(n_before);
             }
@@ -709,7 +733,7 @@ void enqueue_post(rdr_ctx* c, float exposure) {
     (void)hipEventRecord(c->ev[3], c->stream);
     launch_tonemap(c->stream, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, c->d_out.as<uint32_t>(),
                    c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
-    launch_average_luminance(c->stream, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), c->d_lum.as<float>() + 256);
+    launch_average_luminance(c->stream, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), c->d_counters.as<float>() + RDR_COUNTER_LUM);
     (void)hipEventRecord(c->ev[4], c->stream);
     c->have_post = true;
 }
@@ -750,8 +774,9 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
         tables[512 + i] = (float)srgb_eotf(((double)i + 0.5) / 255.0);
     }
     ok = ok && c->d_tables.ensure(768 * 4) == hipSuccess && hipMemcpy(c->d_tables.p, tables.data(), 768 * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && c->d_counters.ensure(64) == hipSuccess && hipMemset(c->d_counters.p, 0, 64) == hipSuccess;
-    ok = ok && c->d_frame.ensure(sizeof(DFrame)) == hipSuccess;
+    ok = ok && c->d_counters.ensure(RDR_COUNTER_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, RDR_COUNTER_BYTES) == hipSuccess;
+    if (ok) c->d_binned.p = c->d_counters.as<uint8_t>() + 64;
+    ok = ok && c->d_frame.ensure(sizeof(DFrame) + 64) == hipSuccess;
     if (!ok) { rdr_destroy(c); return RDR_ERR_DEVICE; }
     c->camera.type = 0;  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
     c->camera.position = make3(0, 0, 0); c->camera.euler = make3(0, 0, 0);
@@ -774,12 +799,12 @@ void rdr_destroy(rdr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->d_pos, &c->d_attr, &c->d_idx, &c->d_prims, &c->d_textures, &c->d_lights, &c->d_tables, &c->d_trig, &c->d_env,
+    DevBuf* bufs[] = {&c->d_pos, &c->d_attr, &c->d_idx, &c->d_prims, &c->d_textures, &c->d_tables, &c->d_trig, &c->d_env,
                       &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
-                      &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_views, &c->d_draws,
-                      &c->d_draw_first, &c->d_first_tri, &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start, &c->d_tile_end,
-                      &c->d_counters, &c->d_binned, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_frag_used, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
-                      &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_first, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
+                      &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
+                      &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
+                      &c->d_counters, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
@@ -1208,9 +1233,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     HIP_TRY(c->d_depth.ensure(n * S * 4));
     HIP_TRY(c->d_vis.ensure(n * S * 4));
     c->stats = rdr_frame_stats{};
-    HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, 64, c->stream));
-    HIP_TRY(c->d_binned.ensure(RDR_BINNED_SLOTS * 128));
-    HIP_TRY(hipMemsetAsync(c->d_binned.p, 0, RDR_BINNED_SLOTS * 128, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, RDR_COUNTER_BYTES, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const vec3 cam_pos = c->camera.position;
     const mat4 viewproj = c->camera.view_proj();
@@ -1276,7 +1299,9 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
             const HostLight& l = c->lights[i];
             dl[i] = DPointLight{l.point.x, l.point.y, l.point.z, l.intensity.x, l.intensity.y, l.intensity.z, l.flags, l.slot};
         }
-        HIP_TRY(c->d_lights.ensure(dl.size() * sizeof(DPointLight)));
+        const size_t sz_l = dl.size() * sizeof(DPointLight), off_l = (sizeof(DFrame) + 15) & ~(size_t)15;
+        HIP_TRY(c->d_frame.ensure(off_l + sz_l));
+        c->d_lights.p = c->d_frame.as<uint8_t>() + off_l;
         fr.lights = c->d_lights.as<DPointLight>();
         fr.env = c->env; fr.irradiance = c->irradiance; fr.prefiltered = c->prefiltered;
         fr.lut = c->d_lut.as<uint8_t>(); fr.lut_w = c->lut_w; fr.lut_h = c->lut_h;
@@ -1285,13 +1310,11 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         fr.srgb_decode = c->d_tables.as<float>(); fr.unorm_decode = c->d_tables.as<float>() + 256;
         fr.tex_white = 0; fr.tex_normal = 1;
         // its own pinned block: the previous frame's copy out of it finished before that frame's pair count arrived
-        const size_t sz_l = dl.size() * sizeof(DPointLight);
-        HIP_TRY(c->h_frame.ensure(sizeof(DFrame) + sz_l + 64));
+        HIP_TRY(c->h_frame.ensure(off_l + sz_l + 64));
         uint8_t* st = c->h_frame.as<uint8_t>();
         memcpy(st, &fr, sizeof fr);
-        memcpy(st + sizeof fr, dl.data(), sz_l);
-        HIP_TRY(hipMemcpyAsync(c->d_frame.p, st, sizeof fr, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_lights.p, st + sizeof fr, sz_l, hipMemcpyHostToDevice, c->stream));
+        memcpy(st + off_l, dl.data(), sz_l);
+        HIP_TRY(hipMemcpyAsync(c->d_frame.p, st, off_l + sz_l, hipMemcpyHostToDevice, c->stream));
 
         // d_draws / d_first_tri hold the whole batch; a view's draws are a slice
         HIP_TRY(c->d_shade_tris.ensure(std::max<size_t>((size_t)n_main_tris + n_blend_tris, 1) * sizeof(DShadeTri)));
@@ -1334,11 +1357,10 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         HIP_TRY(c->d_frags.ensure(capacity * 16));
         HIP_TRY(c->d_frag_col.ensure(capacity * 16));
         HIP_TRY(c->d_frag_head.ensure(n * 4));
-        HIP_TRY(c->d_frag_used.ensure(64));
         launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
                             c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
                             c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p, c->d_frag_col.p,
-                            c->d_frag_head.as<uint32_t>(), c->d_frag_used.as<uint32_t>(), (uint32_t)capacity);
+                            c->d_frag_head.as<uint32_t>(), c->d_counters.as<uint32_t>() + RDR_COUNTER_FRAGS, (uint32_t)capacity);
         HIP_TRY(hipGetLastError());
     }
 
@@ -1349,9 +1371,9 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     HIP_TRY(hipGetLastError());
     c->have_frame = true;
     c->stats.exposure = exposure;
-    HIP_TRY(c->h_read.ensure(64 + RDR_BINNED_SLOTS * 128));
-    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 16, c->d_lum.as<float>() + 256, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + 64, c->d_binned.p, RDR_BINNED_SLOTS * 128, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c->h_read.ensure(RDR_READ_BYTES));
+    // the average luminance (word RDR_COUNTER_LUM) and the spread counters, one copy
+    HIP_TRY(hipMemcpyAsync(c->h_read.p, c->d_counters.p, RDR_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
     if (out_rgba8) HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     // With a device destination the call only enqueues; rdr_synchronize() (or the next frame's first
@@ -1367,7 +1389,7 @@ int rdr_synchronize(rdr_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->have_frame && c->h_read.p) {
-        memcpy(&c->last_avg_log_lum, c->h_read.as<uint8_t>() + 16, 4);
+        memcpy(&c->last_avg_log_lum, c->h_read.as<float>() + RDR_COUNTER_LUM, 4);
         uint32_t binned = 0, chunks_culled = 0;
         for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
             binned += c->h_read.as<uint32_t>()[16 + k * 32];
@@ -1498,7 +1520,7 @@ int rdr_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, c->d_out.p, n * 4, hipMemcpyDeviceToHost));
-    if (out_avg) HIP_TRY(hipMemcpy(out_avg, c->d_lum.as<float>() + 256, 4, hipMemcpyDeviceToHost));
+    if (out_avg) HIP_TRY(hipMemcpy(out_avg, c->d_counters.as<float>() + RDR_COUNTER_LUM, 4, hipMemcpyDeviceToHost));
     return RDR_OK;
 }
 

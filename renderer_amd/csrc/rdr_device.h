@@ -53,13 +53,14 @@ struct DTexture {
 // One raster view (a shadow-map face, a cascade, or the main camera).
 struct DView {
     float* depth;        // [samples][h][w]
+    const float* init;   // load == 1: where the depth the view starts from is read (same layout); may be `depth` itself
     uint32_t* vis;       // same layout, or null for depth-only views
     uint32_t w, h;
     uint32_t samples;    // 1 or 4
     uint32_t cull;       // 0 none, 1 front, 2 back
     uint32_t tiles_x, tiles_y;
     uint32_t tile_base;  // first global tile id of this view
-    uint32_t load;       // 0: clear depth to 1.0 first, 1: keep what the target holds, 2: binned only (the blended pass rasterises it)
+    uint32_t load;       // 0: start from depth 1.0, 1: start from what `init` holds, 2: binned only (the blended pass rasterises it)
 };
 
 // One draw = one primitive seen from one view.
