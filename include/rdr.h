@@ -215,6 +215,7 @@ typedef struct rdr_frame_stats {
     uint64_t chunks_culled;       /* 64-triangle chunks whose bounding box the GPU culling pre-pass found outside a
                                    * view (their triangles skip set-up); 0 from the CPU checker, which has no such
                                    * pre-pass. The reference culls whole primitives only (VulkanRenderer.cpp:929-943). */
+    uint64_t frame_index;         /* which rdr_render_frame call of this context these numbers belong to, counted from 1 */
 } rdr_frame_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -297,7 +298,14 @@ int rdr_set_exposure_bias(rdr_ctx* ctx, float exposure_bias, float gamma);
  * average luminance. `out_rgba8` receives width*height*4 bytes, row 0 first;
  * it is a host pointer, or a device pointer when out_is_device != 0 (then the
  * call only enqueues work on the context's stream; use rdr_synchronize).
- * NULL skips the copy. */
+ * NULL skips the copy.
+ *
+ * Frames in flight (the reference keeps two, VulkanRenderer.cpp:1013-1030): with a device destination the next
+ * rdr_render_frame may be called without rdr_synchronize in between. It builds and enqueues its shadow and
+ * geometry work while the GPU finishes the previous frame, and by the time it returns the previous frame is
+ * complete: its image is in its destination and rdr_get_frame_stats describes it (frame_index tells which
+ * frame the numbers belong to). rdr_synchronize waits for everything enqueued; after it rdr_get_frame_stats
+ * describes the last frame. */
 int rdr_render_frame(rdr_ctx* ctx, const rdr_frame_params* params, uint8_t* out_rgba8, int out_is_device,
                      float* out_avg_log_luminance);
 int rdr_synchronize(rdr_ctx* ctx);

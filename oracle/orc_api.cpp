@@ -642,7 +642,9 @@ static float compute_exposure(Ctx& c, const rdr_frame_params* fp) {
 int orc_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int, float* out_avg) {
     if (!c) return RDR_ERR_INVALID;
     const uint32_t W = c->W, H = c->H, S = c->settings.msaa;
+    const uint64_t frame_index = c->stats.frame_index + 1;  // frames are rendered to completion, one at a time
     c->stats = rdr_frame_stats{};
+    c->stats.frame_index = frame_index;
     const V3 cam_pos = c->camera.position;
     const M4 viewproj = c->camera.viewProj();
     if (c->lights_set) {

@@ -24,14 +24,15 @@ using namespace rdr;
 
 namespace {
 
-// d_counters: 64 bytes of scalar counters, then the spread counters. h_read (pinned): [0, RDR_COUNTER_BYTES) is what the
-// end of a frame reads back (average luminance in word RDR_COUNTER_LUM, spread counters from byte 64), [RDR_READ_MID, +RDR_COUNTER_BYTES)
-// what a batch reads back between its pair scan and its sort.
+// d_counters: 64 bytes of scalar counters, then the spread counters. h_read (pinned) holds three copies of that block:
+// [s * RDR_COUNTER_BYTES, +RDR_COUNTER_BYTES) for s = 0, 1 is what the end of a frame in slot s reads back (average
+// luminance in word RDR_COUNTER_LUM, spread counters from byte 64), [RDR_READ_MID, +RDR_COUNTER_BYTES) what a batch
+// reads back between its pair scan and its sort.
 #define RDR_COUNTER_BYTES (64u + RDR_BINNED_SLOTS * 128u)
 #define RDR_COUNTER_LUM 4u  // word of the scalar counters that the luminance reduction writes its result to
 #define RDR_COUNTER_FRAGS 5u  // word the blended pass counts its fragment-list slots in (zero after the frame's fill)
-#define RDR_READ_MID RDR_COUNTER_BYTES
-#define RDR_READ_BYTES (2u * RDR_COUNTER_BYTES)
+#define RDR_READ_MID (2u * RDR_COUNTER_BYTES)
+#define RDR_READ_BYTES (3u * RDR_COUNTER_BYTES)
 
 struct DevBuf {
     void* p = nullptr;
@@ -173,8 +174,16 @@ struct rdr_ctx {
     DevBuf d_frags, d_frag_col, d_frag_head;  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
 
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
-    rdr_frame_stats stats{};
-    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // Two frames can be in flight: a frame rendered into a device destination is only enqueued, and the next call builds
+    // and enqueues its first half while the GPU still works on this one. Each keeps its own events and its own block
+    // of the pinned read-back area until its results are picked up (harvest()).
+    rdr_frame_stats stats{};       // host-side counters of the frame being enqueued
+    rdr_frame_stats done_stats{};  // the newest frame whose results have been picked up: what rdr_get_frame_stats returns
+    struct PendingFrame { bool on = false; rdr_frame_stats host{}; } pending[2];
+    uint64_t frames = 0;           // frames enqueued so far
+    int slot = 0;                  // frames & 1 of the frame being enqueued
+    hipEvent_t ev_sets[2][10] = {};
+    hipEvent_t* ev = ev_sets[0];   // the events of the frame being enqueued
     hipEvent_t ev_pairs = nullptr;  // the pair count of the batch being binned has reached the host
     PinBuf h_frame;                 // staging of DFrame + lights (h_stage is busy with the batch tables at that point)
 };
@@ -426,6 +435,35 @@ int create_image(rdr_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h, bool s
     return RDR_OK;
 }
 
+// Picks up the results of the frame in `slot` (it must have finished on the GPU): luminance, device-side counters, pass
+// times. Idempotent.
+void harvest(rdr_ctx* c, int slot) {
+    if (!c->pending[slot].on) return;
+    rdr_frame_stats st = c->pending[slot].host;
+    const uint8_t* rd = c->h_read.as<uint8_t>() + (size_t)slot * RDR_COUNTER_BYTES;
+    memcpy(&c->last_avg_log_lum, rd + 4 * RDR_COUNTER_LUM, 4);
+    uint32_t binned = 0, chunks_culled = 0;
+    for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
+        const uint32_t* w = (const uint32_t*)(rd + 64 + k * 128);
+        binned += w[0];
+        chunks_culled += w[4];
+    }
+    st.triangles_binned = binned;
+    st.chunks_culled = chunks_culled;
+    st.avg_log_luminance = c->last_avg_log_lum;
+    hipEvent_t* ev = c->ev_sets[slot];
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) st.ms_geometry = ms;
+    if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) st.ms_shade = ms;
+    if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) st.ms_bloom = ms;
+    if (hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess) st.ms_tonemap = ms;
+    if (hipEventElapsedTime(&ms, ev[0], ev[5]) == hipSuccess) st.ms_total = ms;
+    if (hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) st.ms_shade_kernel = ms;
+    if (hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) st.ms_raster_kernel = ms;
+    c->done_stats = st;
+    c->pending[slot].on = false;
+}
+
 // Runs set-up -> bin -> sort for one batch of views. On return the sorted
 // triangle lists of every tile are in d_vals[*cur] / d_tile_start / d_tile_end.
 int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std::function<int()>& after_scan) {
@@ -486,6 +524,7 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     HIP_TRY(hipEventRecord(c->ev_pairs, c->stream));
     if (after_scan) RDR_TRY(after_scan());
     HIP_TRY(hipEventSynchronize(c->ev_pairs));
+    harvest(c, c->slot ^ 1);  // everything enqueued before this batch has finished, the previous frame with it
     const uint32_t* mid = (const uint32_t*)(c->h_read.as<uint8_t>() + RDR_READ_MID);
     const uint32_t n_pairs = mid[0];
     // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
@@ -764,7 +803,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     c->settings = *settings; c->W = width; c->H = height; c->device = device;
     memset(&c->dir_light, 0, sizeof c->dir_light);
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
-    for (int i = 0; i < 10 && ok; i++) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+    for (int i = 0; i < 20 && ok; i++) ok = hipEventCreate(&c->ev_sets[i / 10][i % 10]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_pairs, hipEventDisableTiming) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
     std::vector<float> tables(768);
@@ -808,7 +847,7 @@ void rdr_destroy(rdr_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
-    for (int i = 0; i < 10; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 20; i++) if (c->ev_sets[i / 10][i % 10]) (void)hipEventDestroy(c->ev_sets[i / 10][i % 10]);
     if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
     c->h_frame.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1232,7 +1271,14 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     RDR_TRY(ensure_post_targets(c));
     HIP_TRY(c->d_depth.ensure(n * S * 4));
     HIP_TRY(c->d_vis.ensure(n * S * 4));
+    c->slot = (int)(c->frames & 1u);
+    c->ev = c->ev_sets[c->slot];
+    if (c->pending[c->slot].on) {  // the frame before the previous one was never picked up: it has long finished
+        HIP_TRY(hipEventSynchronize(c->ev[5]));
+        harvest(c, c->slot);
+    }
     c->stats = rdr_frame_stats{};
+    c->stats.frame_index = ++c->frames;
     HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, RDR_COUNTER_BYTES, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const vec3 cam_pos = c->camera.position;
@@ -1373,11 +1419,14 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     c->stats.exposure = exposure;
     HIP_TRY(c->h_read.ensure(RDR_READ_BYTES));
     // the average luminance (word RDR_COUNTER_LUM) and the spread counters, one copy
-    HIP_TRY(hipMemcpyAsync(c->h_read.p, c->d_counters.p, RDR_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES, c->d_counters.p, RDR_COUNTER_BYTES,
+                           hipMemcpyDeviceToHost, c->stream));
     if (out_rgba8) HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
-    // With a device destination the call only enqueues; rdr_synchronize() (or the next frame's first
-    // internal synchronisation) picks up the luminance and the counters.
+    c->pending[c->slot].on = true;
+    c->pending[c->slot].host = c->stats;
+    // With a device destination the call only enqueues; rdr_synchronize(), or the next frame once its own triangle
+    // set-up has run, picks up the luminance and the counters.
     if (out_is_device && out_rgba8) return RDR_OK;
     RDR_TRY(rdr_synchronize(c));
     if (out_avg) *out_avg = c->last_avg_log_lum;
@@ -1388,31 +1437,14 @@ int rdr_synchronize(rdr_ctx* c) {
     if (!c) return RDR_ERR_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->have_frame && c->h_read.p) {
-        memcpy(&c->last_avg_log_lum, c->h_read.as<float>() + RDR_COUNTER_LUM, 4);
-        uint32_t binned = 0, chunks_culled = 0;
-        for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
-            binned += c->h_read.as<uint32_t>()[16 + k * 32];
-            chunks_culled += c->h_read.as<uint32_t>()[16 + k * 32 + 4];
-        }
-        c->stats.triangles_binned = binned;
-        c->stats.chunks_culled = chunks_culled;
-        c->stats.avg_log_luminance = c->last_avg_log_lum;
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_geometry = ms;
-        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_shade = ms;
-        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_bloom = ms;
-        if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->stats.ms_tonemap = ms;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->stats.ms_total = ms;
-        if (hipEventElapsedTime(&ms, c->ev[6], c->ev[7]) == hipSuccess) c->stats.ms_shade_kernel = ms;
-        if (hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) c->stats.ms_raster_kernel = ms;
-    }
+    harvest(c, c->slot ^ 1);  // the older frame first, so that done_stats ends up holding the newest
+    harvest(c, c->slot);
     return RDR_OK;
 }
 
 int rdr_get_frame_stats(rdr_ctx* c, rdr_frame_stats* out) {
     if (!c || !out) return RDR_ERR_INVALID;
-    *out = c->stats;
+    *out = c->done_stats;
     return RDR_OK;
 }
 
@@ -1505,7 +1537,7 @@ int rdr_read_image_level(rdr_ctx* c, uint32_t image, uint32_t level, uint8_t* ou
 
 int rdr_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_rgba8, float* out_avg) {
     if (!c || !hdr) return fail(c, RDR_ERR_INVALID, "post_process: null");
-    HIP_TRY(hipSetDevice(c->device));
+    RDR_TRY(rdr_synchronize(c));  // frames in flight finish and hand over their results before their events are reused
     RDR_TRY(ensure_post_targets(c));
     const size_t n = (size_t)c->W * c->H;
     // quantise to RGBA16F on the host (round to nearest even) exactly like the colour attachment would store it

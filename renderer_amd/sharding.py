@@ -7,8 +7,12 @@ process per GPU, `torch.distributed` with the "nccl" backend (RCCL over xGMI);
 the same code runs with "gloo" and host tensors, which is how it is tested
 without GPUs.
 
-The gather of frame k is issued asynchronously and waited for only when its
-staging slot is needed again, so it overlaps the rendering of the next frames.
+Two frames are in flight on a GPU: frame k is only enqueued, the host goes on to
+build and enqueue frame k+1 behind it, and frame k's image and luminance are
+collected when that call returns (the renderer guarantees frame k is complete
+by then). The gather of frame k is issued asynchronously at that point and
+waited for only when its staging slot is needed again, so it overlaps the
+rendering of the next frames.
 Rank 0 receives over up to R-1 distinct xGMI links at once (a 4K RGBA8 frame is
 33 MB, about 0.2 ms per link), which is why a plain gather is used rather than
 a ring all-gather.
@@ -60,13 +64,24 @@ class FrameSharder:
 
     # -- one frame ---------------------------------------------------------
     def _render_into(self, tensor, frame_params):
+        """Renders into `tensor`. A device tensor only gets the frame enqueued (returns None: the frame's results are
+        picked up by `_collect` once the next frame has been enqueued behind it, or after `synchronize`); a host
+        tensor is rendered to completion and its average log-luminance returned."""
         if tensor.is_cuda:
             self.r.render_frame(device_ptr=tensor.data_ptr(), **frame_params)
-            self.r.synchronize()
-            return self.r.frame_stats().avg_log_luminance
+            return None
         out = tensor.numpy()
         _, avg = self.r.render_frame(out=out, **frame_params)
         return avg
+
+    def _collect(self, k, first_index, after_render):
+        """Frame k of this rank has finished on its GPU: record its luminance, run the per-frame hook."""
+        s = self.r.frame_stats()
+        if s.frame_index != first_index + k // self.world:
+            raise RuntimeError(f"frame statistics out of step: expected frame {first_index + k // self.world} of the context, got {s.frame_index}")
+        self.luminance[k] = s.avg_log_luminance
+        if after_render is not None:
+            after_render(k)
 
     def _retire(self, slot, on_frames):
         if self.pending[slot] is None:
@@ -88,20 +103,51 @@ class FrameSharder:
         this rank."""
         frame_params = dict(frame_params or {})
         n_rounds = rounds(n_frames, self.world)
+        first_index = self.r.frame_stats().frame_index + 1 if self.slots[0].is_cuda else 0  # index of this job's frame 0
+        in_flight = None  # (round, frame) enqueued on the GPU whose results have not been collected yet
+
+        def finish(entry):
+            # the frame is complete: collect its results, then hand its image to the gather
+            rnd_f, k_f = entry
+            if k_f is not None:
+                self._collect(k_f, first_index, after_render)
+            slot_f = rnd_f % self.depth
+            n_valid = min(self.world, n_frames - rnd_f * self.world)
+            work = None
+            if self.dist:
+                work = self.dist.gather(self.slots[slot_f], self.recv[slot_f] if self.rank == 0 else None, dst=0, async_op=True)
+            self.pending[slot_f] = (work, rnd_f, n_valid)
+
         for rnd in range(n_rounds):
             slot = rnd % self.depth
             self._retire(slot, on_frame)
             k = rnd * self.world + self.rank
+            avg = None
             if k < n_frames:
                 set_frame(self.r, k)
-                self.luminance[k] = self._render_into(self.slots[slot], frame_params)
-                if after_render is not None:
-                    after_render(k)
-            n_valid = min(self.world, n_frames - rnd * self.world)
-            work = None
-            if self.dist:
-                work = self.dist.gather(self.slots[slot], self.recv[slot] if self.rank == 0 else None, dst=0, async_op=True)
-            self.pending[slot] = (work, rnd, n_valid)
+                avg = self._render_into(self.slots[slot], frame_params)
+            if self.slots[slot].is_cuda:
+                # two frames in flight: frame k was only enqueued, and by now the frame before it has finished
+                # (a rank without a frame in this round enqueued nothing behind it and has to wait for it)
+                if in_flight is not None:
+                    if k >= n_frames:
+                        self.r.synchronize()
+                    finish(in_flight)
+                in_flight = (rnd, k if k < n_frames else None)
+            else:
+                if k < n_frames:
+                    self.luminance[k] = avg
+                    if after_render is not None:
+                        after_render(k)
+                in_flight = None
+                n_valid = min(self.world, n_frames - rnd * self.world)
+                work = None
+                if self.dist:
+                    work = self.dist.gather(self.slots[slot], self.recv[slot] if self.rank == 0 else None, dst=0, async_op=True)
+                self.pending[slot] = (work, rnd, n_valid)
+        if in_flight is not None:
+            self.r.synchronize()
+            finish(in_flight)
         # drain in round order
         order = sorted((p[1], s) for s, p in enumerate(self.pending) if p is not None)
         for _, s in order:

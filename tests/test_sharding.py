@@ -103,3 +103,54 @@ def test_exposure_sequence_follows_the_reference_recurrence():
     t2 = t1 + (2.0 ** 2.0 - t1) * g
     assert np.allclose(tl, [t0, t1, t2], rtol=1e-6)
     assert np.allclose(ex, [0.18 / (1.03 - 2.0 / (np.log2(t + 1.0) + 2.0)) for t in (t0, t1, t2)], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi):
+    """Frames enqueued back to back into device tensors (the sharder keeps two in flight and collects frame k after
+    frame k+1 has been enqueued) against the same frames rendered to completion one at a time: same images, same
+    per-frame luminance and counters, and the statistics carry the right frame index."""
+    import torch
+
+    from renderer_amd import scenes
+    from renderer_amd.api import Renderer, default_settings
+
+    W, H, n = 200, 120, 5
+
+    def build():
+        r = Renderer(hip_capi, W, H, default_settings(msaa=4, directional_shadow_map_resolution=512, point_shadow_map_resolution=128))
+        scenes.small_scene(r)
+        return r
+
+    def camera(r, k):
+        r.set_camera(position=(0.3 * k - 0.5, 1.2 + 0.1 * k, 4.0 - 0.2 * k), euler=(-0.1, 0.05 * k, 0.0))
+
+    serial, serial_stats = [], []
+    r1 = build()
+    for k in range(n):
+        camera(r1, k)
+        img, avg = r1.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        s = r1.frame_stats()
+        serial.append(img.copy())
+        serial_stats.append((avg, int(s.triangles_binned), int(s.tile_pairs), int(s.frame_index)))
+    r1.close()
+
+    r2 = build()
+    sh = sharding.FrameSharder(r2, dist=None, device="cuda:0", depth=2)
+    piped, piped_stats = {}, {}
+
+    def after_render(k):
+        s = r2.frame_stats()
+        piped_stats[k] = (float(s.avg_log_luminance), int(s.triangles_binned), int(s.tile_pairs), int(s.frame_index))
+        assert s.ms_total > 0.0 and s.ms_shade_kernel > 0.0
+
+    lum = sh.run(n, camera, dict(exposure_mode=1, temporal_luminance=0.5), on_frame=lambda k, t: piped.__setitem__(k, t.cpu().numpy().copy()),
+                 after_render=after_render)
+    torch.cuda.synchronize()
+    r2.close()
+    assert sorted(piped) == list(range(n)) and sorted(piped_stats) == list(range(n))
+    for k in range(n):
+        assert np.array_equal(piped[k], serial[k]), f"frame {k}"
+        assert piped_stats[k][1:] == serial_stats[k][1:], f"counters of frame {k}"
+        assert piped_stats[k][0] == serial_stats[k][0] == lum[k], f"luminance of frame {k}"
+        assert piped_stats[k][3] == k + 1
