@@ -185,7 +185,7 @@ struct rdr_ctx {
     hipEvent_t ev_sets[2][10] = {};
     hipEvent_t* ev = ev_sets[0];   // the events of the frame being enqueued
     hipEvent_t ev_pairs = nullptr;  // the pair count of the batch being binned has reached the host
-    PinBuf h_frame;                 // staging of DFrame + lights (h_stage is busy with the batch tables at that point)
+    PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
 };
 
 namespace {
@@ -1356,9 +1356,11 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         fr.pos = c->d_pos.as<float4>(); fr.attr = c->d_attr.as<DVertexAttr>(); fr.idx = c->d_idx.as<uint32_t>();
         fr.srgb_decode = c->d_tables.as<float>(); fr.unorm_decode = c->d_tables.as<float>() + 256;
         fr.tex_white = 0; fr.tex_normal = 1;
-        // its own pinned block: the previous frame's copy out of it finished before that frame's pair count arrived
-        HIP_TRY(c->h_frame.ensure(off_l + sz_l + 64));
-        uint8_t* st = c->h_frame.as<uint8_t>();
+        // its own pinned block, one half per frame slot: the copy out of a half was enqueued two frames ago, in front
+        // of work the previous frame's pair-count wait has since seen finished
+        const size_t half = (off_l + sz_l + 63) & ~(size_t)63;
+        HIP_TRY(c->h_frame.ensure(2 * half));
+        uint8_t* st = c->h_frame.as<uint8_t>() + (size_t)c->slot * half;
         memcpy(st, &fr, sizeof fr);
         memcpy(st + off_l, dl.data(), sz_l);
         HIP_TRY(hipMemcpyAsync(c->d_frame.p, st, off_l + sz_l, hipMemcpyHostToDevice, c->stream));
