@@ -758,7 +758,8 @@ int ensure_post_targets(rdr_ctx* c) {
 }
 
 // bloom chain + tonemap + average luminance (VulkanRendererBloom.cpp:62-100, VulkanRenderer.cpp:1084-1109, 1156-1191)
-void enqueue_post(rdr_ctx* c, float exposure) {
+// `direct_out`: a device destination the tonemap kernel writes the finished frame to instead of d_out (8-byte aligned)
+void enqueue_post(rdr_ctx* c, float exposure, uint32_t* direct_out = nullptr) {
     uint32_t* bloom = c->d_bloom.as<uint32_t>();
     (void)hipEventRecord(c->ev[2], c->stream);
     // mip 0 is the colour image itself until the tonemap kernel stores its final value
@@ -771,7 +772,7 @@ void enqueue_post(rdr_ctx* c, float exposure) {
                         (int)(c->W >> dl), (int)(c->H >> dl), (int)c->bloom_w[dl]);
     }
     (void)hipEventRecord(c->ev[3], c->stream);
-    launch_tonemap(c->stream, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, c->d_out.as<uint32_t>(),
+    launch_tonemap(c->stream, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, direct_out ? direct_out : c->d_out.as<uint32_t>(),
                    c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
     launch_average_luminance(c->stream, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), c->d_counters.as<float>() + RDR_COUNTER_LUM);
     (void)hipEventRecord(c->ev[4], c->stream);
@@ -1415,7 +1416,9 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     // ---- bloom, tonemap, luminance
     if (c->have_frame && (!fp || fp->exposure_mode == 0)) RDR_TRY(rdr_synchronize(c));  // previous frame's luminance
     const float exposure = compute_exposure(c, fp);
-    enqueue_post(c, exposure);
+    // a device destination receives the frame straight from the tonemap kernel (its 8-byte stores need the alignment)
+    uint32_t* direct_out = (out_rgba8 && out_is_device && ((uintptr_t)out_rgba8 & 7u) == 0) ? (uint32_t*)out_rgba8 : nullptr;
+    enqueue_post(c, exposure, direct_out);
     HIP_TRY(hipGetLastError());
     c->have_frame = true;
     c->stats.exposure = exposure;
@@ -1423,7 +1426,8 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     // the average luminance (word RDR_COUNTER_LUM) and the spread counters, one copy
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES, c->d_counters.p, RDR_COUNTER_BYTES,
                            hipMemcpyDeviceToHost, c->stream));
-    if (out_rgba8) HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (out_rgba8 && !direct_out)
+        HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev[5], c->stream));
     c->pending[c->slot].on = true;
     c->pending[c->slot].host = c->stats;

@@ -89,6 +89,10 @@ class FrameSharder:
         work, rnd, n_valid = self.pending[slot]
         if work is not None:
             work.wait()
+            if self.device.type == "cuda":
+                # wait() only orders torch's current stream behind the gather; the renderer writes this slot from its
+                # own stream, so the host makes sure the gather (issued a frame ago) has really finished
+                self.torch.cuda.current_stream(self.device).synchronize()
         self.pending[slot] = None
         if on_frames is not None and self.rank == 0:
             imgs = self.recv[slot] if self.recv is not None else [self.slots[slot]]
