@@ -269,6 +269,9 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
             Lv[j] = f3(pl.px, pl.py, pl.pz) - P;
             d2[j] = dot3(Lv[j], Lv[j]);  // distance^2
             sh[j] = 1.0f;
+            // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says:
+            // neither the shadow map nor the BRDF is evaluated for it.
+            if (!(dot3(N, Lv[j]) > 0.0f)) { sh[j] = 0.0f; continue; }
             if ((pl.flags & 1u) && (pl.flags & 2u) && !(RDR_DIAG & 32)) {
                 const float lightDepth = fmaxf(fabsf(Lv[j].x), fmaxf(fabsf(Lv[j].y), fabsf(Lv[j].z))) - 0.05f;
                 const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
@@ -292,7 +295,8 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     }
 
     // ---- directional light with cascaded shadow maps (pbr.frag:163-183, basic.vert:45-48)
-    if (fr.lights_set && !(RDR_DIAG & 2)) {
+    // (a surface facing away from the light gets max(N.L, 0) = 0 from it: no cascade look-up, no BRDF)
+    if (fr.lights_set && !(RDR_DIAG & 2) && dot3(N, f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2])) > 0.0f) {
         const int ncasc = (int)fr.n_cascades, res = (int)fr.dir_res;
         int split = 0;
         float ls0 = 0.0f, ls1 = 0.0f, ls2 = 0.0f;
