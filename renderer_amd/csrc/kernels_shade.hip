@@ -237,8 +237,12 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     const float roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
     RDR_SAMPLE_SLOT(3, 1)
     const float ao = t[0] * mt.ao;
-    RDR_SAMPLE_SLOT(4, 7)
-    const float emissive[3] = {t[0] * mt.emissive[0], t[1] * mt.emissive[1], t[2] * mt.emissive[2]};
+    // a zero emissive factor (the glTF default) makes the product zero whatever the texel is: no fetch
+    float emissive[3] = {0.0f, 0.0f, 0.0f};
+    if (mt.emissive[0] != 0.0f || mt.emissive[1] != 0.0f || mt.emissive[2] != 0.0f) {
+        RDR_SAMPLE_SLOT(4, 7)
+        emissive[0] = t[0] * mt.emissive[0]; emissive[1] = t[1] * mt.emissive[1]; emissive[2] = t[2] * mt.emissive[2];
+    }
     RDR_SAMPLE_SLOT(1, 7)
 #undef RDR_SAMPLE_SLOT
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
