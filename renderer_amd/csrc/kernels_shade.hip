@@ -74,8 +74,12 @@ RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, f
 
 RDR_DEV DPointLight load_light(const DPointLight* p) {
     const RDR_GLOBAL DPointLight* g = as_global(p);
+    // every lane reads the same light: the values are moved to scalar registers, which the 128-register budget of the
+    // shading kernels is not charged for
+    auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
     DPointLight l;
-    l.px = g->px; l.py = g->py; l.pz = g->pz; l.ix = g->ix; l.iy = g->iy; l.iz = g->iz; l.flags = g->flags; l.slot = g->slot;
+    l.px = uni(g->px); l.py = uni(g->py); l.pz = uni(g->pz); l.ix = uni(g->ix); l.iy = uni(g->iy); l.iz = uni(g->iz);
+    l.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)g->flags); l.slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)g->slot);
     return l;
 }
 
