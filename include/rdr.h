@@ -305,7 +305,8 @@ int rdr_set_exposure_bias(rdr_ctx* ctx, float exposure_bias, float gamma);
  * geometry work while the GPU finishes the previous frame, and by the time it returns the previous frame is
  * complete: its image is in its destination and rdr_get_frame_stats describes it (frame_index tells which
  * frame the numbers belong to). rdr_synchronize waits for everything enqueued; after it rdr_get_frame_stats
- * describes the last frame. */
+ * describes the last frame. Results are handed over at those two points only (never by rdr_get_frame_stats
+ * itself), so which frame the statistics describe does not depend on timing. */
 int rdr_render_frame(rdr_ctx* ctx, const rdr_frame_params* params, uint8_t* out_rgba8, int out_is_device,
                      float* out_avg_log_luminance);
 int rdr_synchronize(rdr_ctx* ctx);
