@@ -106,10 +106,13 @@ def test_exposure_sequence_follows_the_reference_recurrence():
 
 
 @pytest.mark.gpu
-def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi):
+@pytest.mark.parametrize("exposure_mode", [1, 0])
+def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi, exposure_mode):
     """Frames enqueued back to back into device tensors (the sharder keeps two in flight and collects frame k after
     frame k+1 has been enqueued) against the same frames rendered to completion one at a time: same images, same
-    per-frame luminance and counters, and the statistics carry the right frame index."""
+    per-frame luminance and counters, and the statistics carry the right frame index. With exposure_mode 0 every
+    frame's exposure follows from the luminance of the frame before it (the reference's recurrence), which the
+    renderer has to wait for in the middle of the next frame."""
     import torch
 
     from renderer_amd import scenes
@@ -129,7 +132,7 @@ def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi):
     r1 = build()
     for k in range(n):
         camera(r1, k)
-        img, avg = r1.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        img, avg = r1.render_frame(exposure_mode=exposure_mode, temporal_luminance=0.5, delta_time=1.0 / 30.0)
         s = r1.frame_stats()
         serial.append(img.copy())
         serial_stats.append((avg, int(s.triangles_binned), int(s.tile_pairs), int(s.frame_index)))
@@ -144,7 +147,7 @@ def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi):
         piped_stats[k] = (float(s.avg_log_luminance), int(s.triangles_binned), int(s.tile_pairs), int(s.frame_index))
         assert s.ms_total > 0.0 and s.ms_shade_kernel > 0.0
 
-    lum = sh.run(n, camera, dict(exposure_mode=1, temporal_luminance=0.5), on_frame=lambda k, t: piped.__setitem__(k, t.cpu().numpy().copy()),
+    lum = sh.run(n, camera, dict(exposure_mode=exposure_mode, temporal_luminance=0.5, delta_time=1.0 / 30.0), on_frame=lambda k, t: piped.__setitem__(k, t.cpu().numpy().copy()),
                  after_render=after_render)
     torch.cuda.synchronize()
     r2.close()
