@@ -96,8 +96,8 @@ struct DTexDesc {
 
 // Everything the fragments of one triangle share: the vertex-stage outputs
 // (basic.vert), the material block (pbr.frag:21-37) and its five texture
-// descriptors. Written once per frame by the shading set-up kernel; the shading
-// kernels stage the records of the triangles a wave touches in LDS.
+// descriptors. Written once per frame by the shading set-up kernel; every fragment
+// reads the record of its triangle in place (neighbouring fragments share it through the caches).
 struct alignas(16) DShadeTri {
     double A[3], B[3], C[3];  // homogeneous barycentric planes: l_k(x,y) = A_k x + B_k y + C_k in NDC
     float wp[9];              // world position, component-major: x0 x1 x2 y0 y1 y2 z0 z1 z2
