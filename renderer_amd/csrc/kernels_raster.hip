@@ -414,21 +414,26 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 
 // threads per tile and records staged per pass: single-sampled views (shadow maps), 4x multisampled view
 #ifndef RDR_RASTER_T1
-#define RDR_RASTER_T1 128
+#define RDR_RASTER_T1 64
 #endif
 #ifndef RDR_RASTER_C1
-#define RDR_RASTER_C1 64
+#define RDR_RASTER_C1 32
 #endif
 #ifndef RDR_RASTER_T4
-#define RDR_RASTER_T4 256
+#define RDR_RASTER_T4 128
 #endif
 #ifndef RDR_RASTER_C4
-#define RDR_RASTER_C4 64
+#define RDR_RASTER_C4 32
 #endif
 
-// One block of T threads per 16x16 tile (T = 128 for shadow views, whose tiles are mostly sparse but include a few on
-// the silhouettes of finely tessellated geometry that hold thousands of sliver triangles; T = 256 for the heavier
-// multisampled main view; measured: 64 / 128 / 256 threads give 207 / 177 / 265 us on the shadow views). Work is spread over (triangle, pixel) items, not over triangles: for every chunk of 64 records the block
+// One block of T threads per 16x16 tile, staging the tile's triangle records C at a time. A tile spends most of its
+// life waiting for two dependent rounds of loads per chunk (the sorted triangle ids, then the records they point at;
+// cycle counters around the phases of a typical tile of the benchmark frame: staging 65 % of the block's time for the
+// main view, 85 % for the shadow views, set-up 6 %, the pixel work 13 %), so what counts is how many tiles a CU has in
+// flight: one wave and 6 KB of LDS per shadow-view tile, two waves and 12.5 KB per tile of the 4x view. Measured on
+// that frame: shadow views (T, C) = (128, 64) 176 us, (64, 64) 189, (64, 32) 158, (64, 16) 211; 4x view (256, 64)
+// 271 us, (128, 64) 221, (128, 32) 216, (128, 16) 263, (64, 32) 234.
+// Work is spread over (triangle, pixel) items, not over triangles: for every chunk of records the block
 // sums the areas of their pixel boxes inside the tile (prefix sum), and thread k takes items k, k+T, ... - so
 // sixteen 2x2-pixel triangles keep one wave busy where a loop over triangles would leave 60 of its 64 lanes idle
 // on each.
