@@ -185,6 +185,10 @@ struct rdr_ctx {
     hipEvent_t ev_sets[2][10] = {};
     hipEvent_t* ev = ev_sets[0];   // the events of the frame being enqueued
     hipEvent_t ev_pairs = nullptr;  // the pair count of the batch being binned has reached the host
+    // The two tile rasterisers of a batch (single-sampled shadow views, 4x view) are independent and neither fills the
+    // GPU's issue slots (their tiles mostly wait): the 4x one runs on a second stream beside the other.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
 };
 
@@ -578,8 +582,21 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
         r.end_tile = v.tile_base + v.tiles_x * v.tiles_y;
     }
     HIP_TRY(hipEventRecord(c->ev[8], c->stream));
-    launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                  c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), rr[0], rr[1]);
+    const RasterRange none = {0xFFFFFFFFu, 0u, 0u};
+    const bool both = rr[0].first_tile < rr[0].end_tile && rr[1].first_tile < rr[1].end_tile;
+    if (both) {
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        launch_raster(c->stream2, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), none, rr[1]);
+        HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+        launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), rr[0], none);
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    } else {
+        launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), rr[0], rr[1]);
+    }
     HIP_TRY(hipGetLastError());
     return RDR_OK;
 }
@@ -807,6 +824,9 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
     for (int i = 0; i < 20 && ok; i++) ok = hipEventCreate(&c->ev_sets[i / 10][i % 10]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_pairs, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreate(&c->stream2) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
     std::vector<float> tables(768);
     for (int i = 0; i < 256; i++) {
@@ -851,6 +871,9 @@ void rdr_destroy(rdr_ctx* c) {
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
     for (int i = 0; i < 20; i++) if (c->ev_sets[i / 10][i % 10]) (void)hipEventDestroy(c->ev_sets[i / 10][i % 10]);
     if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     c->h_frame.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
