@@ -161,8 +161,7 @@ struct rdr_ctx {
     DevBuf d_recs, d_pair_count, d_scan, d_hist;
     DevBuf d_tile_start;    // tile_start[n_tiles] | tile_end[n_tiles], one fill
     DevSpan d_tile_end;
-    DevBuf d_counters;      // 64 bytes of scalar counters | RDR_BINNED_SLOTS x 128 bytes of spread counters, one fill, one read-back
-    DevSpan d_binned;
+    DevBuf d_counters;      // per frame slot: 64 bytes of scalar counters | RDR_BINNED_SLOTS x 128 bytes of spread counters, one fill, one read-back
     DevBuf d_frame;         // DFrame | point lights, one upload
     DevSpan d_lights;
     DevBuf d_keys[2], d_vals[2];
@@ -202,6 +201,10 @@ int hip_fail(rdr_ctx* c, const char* what, hipError_t e) {
 }
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(c, #expr, e_); } while (0)
 #define RDR_TRY(expr) do { int r_ = (expr); if (r_ != RDR_OK) return r_; } while (0)
+
+// counters block of the frame being enqueued (each of the two frame slots has its own: the tail of a frame still
+// writes its block while the next frame has cleared and is filling the other)
+uint32_t* frame_counters(const rdr_ctx* c) { return (uint32_t*)(c->d_counters.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES); }
 
 double srgb_eotf(double v) { return v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); }
 
@@ -519,10 +522,10 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     HIP_TRY(c->d_tile_start.ensure(std::max<size_t>(n_tiles, 1) * 8));
     c->d_tile_end.p = c->d_tile_start.as<uint32_t>() + n_tiles;
     HIP_TRY(c->d_scan.ensure((scan_scratch_words(n_inst) + 16) * 4));
-    uint32_t* counters = c->d_counters.as<uint32_t>();  // [0] pair total, [2] scratch total
+    uint32_t* counters = frame_counters(c);  // [0] pair total, [2] scratch total
     launch_setup(c->stream, c->d_views.as<DView>(), c->d_draws.as<DDraw>(), c->d_draw_first.as<uint32_t>(), n_draws, n_inst,
                  c->d_prims.as<DPrim>(), c->d_pos.p, c->d_idx.as<uint32_t>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(),
-                 c->d_binned.as<uint32_t>(), c->d_chunk_first.as<uint32_t>(), n_chunks, c->d_chunk_bb.p, c->d_chunk_flags.as<uint8_t>());
+                 counters + 16, c->d_chunk_first.as<uint32_t>(), n_chunks, c->d_chunk_bb.p, c->d_chunk_flags.as<uint8_t>());
     launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
     HIP_TRY(c->h_read.ensure(RDR_READ_BYTES));
     // scalar counters and spread counters in one copy; it lands beside the block the end of the frame is read into
@@ -530,7 +533,6 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     HIP_TRY(hipEventRecord(c->ev_pairs, c->stream));
     if (after_scan) RDR_TRY(after_scan());
     HIP_TRY(hipEventSynchronize(c->ev_pairs));
-    harvest(c, c->slot ^ 1);  // everything enqueued before this batch has finished, the previous frame with it
     const uint32_t* mid = (const uint32_t*)(c->h_read.as<uint8_t>() + RDR_READ_MID);
     const uint32_t n_pairs = mid[0];
     // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
@@ -776,23 +778,23 @@ int ensure_post_targets(rdr_ctx* c) {
 
 // bloom chain + tonemap + average luminance (VulkanRendererBloom.cpp:62-100, VulkanRenderer.cpp:1084-1109, 1156-1191)
 // `direct_out`: a device destination the tonemap kernel writes the finished frame to instead of d_out (8-byte aligned)
-void enqueue_post(rdr_ctx* c, float exposure, uint32_t* direct_out = nullptr) {
+void enqueue_post(rdr_ctx* c, hipStream_t st, float exposure, uint32_t* direct_out = nullptr) {
     uint32_t* bloom = c->d_bloom.as<uint32_t>();
-    (void)hipEventRecord(c->ev[2], c->stream);
+    (void)hipEventRecord(c->ev[2], st);
     // mip 0 is the colour image itself until the tonemap kernel stores its final value
     for (uint32_t i = 0; i < 5; i++)
-        launch_bloom_down(c->stream, i == 0 ? c->d_hdr.p : (const void*)(bloom + c->bloom_offset[i]), i == 0, (int)c->bloom_w[i], (int)c->bloom_h[i],
+        launch_bloom_down(st, i == 0 ? c->d_hdr.p : (const void*)(bloom + c->bloom_offset[i]), i == 0, (int)c->bloom_w[i], (int)c->bloom_h[i],
                           bloom + c->bloom_offset[i + 1], (int)(c->W >> (i + 1)), (int)(c->H >> (i + 1)), (int)c->bloom_w[i + 1]);
     for (uint32_t i = 0; i < 4; i++) {
         const uint32_t dl = 4 - i, sl = 5 - i;
-        launch_bloom_up(c->stream, bloom + c->bloom_offset[sl], (int)c->bloom_w[sl], (int)c->bloom_h[sl], bloom + c->bloom_offset[dl],
+        launch_bloom_up(st, bloom + c->bloom_offset[sl], (int)c->bloom_w[sl], (int)c->bloom_h[sl], bloom + c->bloom_offset[dl],
                         (int)(c->W >> dl), (int)(c->H >> dl), (int)c->bloom_w[dl]);
     }
-    (void)hipEventRecord(c->ev[3], c->stream);
-    launch_tonemap(c->stream, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, direct_out ? direct_out : c->d_out.as<uint32_t>(),
+    (void)hipEventRecord(c->ev[3], st);
+    launch_tonemap(st, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, direct_out ? direct_out : c->d_out.as<uint32_t>(),
                    c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
-    launch_average_luminance(c->stream, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), c->d_counters.as<float>() + RDR_COUNTER_LUM);
-    (void)hipEventRecord(c->ev[4], c->stream);
+    launch_average_luminance(st, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), (float*)frame_counters(c) + RDR_COUNTER_LUM);
+    (void)hipEventRecord(c->ev[4], st);
     c->have_post = true;
 }
 
@@ -835,8 +837,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
         tables[512 + i] = (float)srgb_eotf(((double)i + 0.5) / 255.0);
     }
     ok = ok && c->d_tables.ensure(768 * 4) == hipSuccess && hipMemcpy(c->d_tables.p, tables.data(), 768 * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && c->d_counters.ensure(RDR_COUNTER_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, RDR_COUNTER_BYTES) == hipSuccess;
-    if (ok) c->d_binned.p = c->d_counters.as<uint8_t>() + 64;
+    ok = ok && c->d_counters.ensure(2 * RDR_COUNTER_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, 2 * RDR_COUNTER_BYTES) == hipSuccess;
     ok = ok && c->d_frame.ensure(sizeof(DFrame) + 64) == hipSuccess;
     if (!ok) { rdr_destroy(c); return RDR_ERR_DEVICE; }
     c->camera.type = 0;  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
@@ -860,6 +861,7 @@ void rdr_destroy(rdr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     DevBuf* bufs[] = {&c->d_pos, &c->d_attr, &c->d_idx, &c->d_prims, &c->d_textures, &c->d_tables, &c->d_trig, &c->d_env,
                       &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
@@ -1304,7 +1306,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     }
     c->stats = rdr_frame_stats{};
     c->stats.frame_index = ++c->frames;
-    HIP_TRY(hipMemsetAsync(c->d_counters.p, 0, RDR_COUNTER_BYTES, c->stream));
+    HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_BYTES, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const vec3 cam_pos = c->camera.position;
     const mat4 viewproj = c->camera.view_proj();
@@ -1395,12 +1397,12 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         tris_blend = tris_main + n_main_tris;
         launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_main_draw, c->d_first_tri.as<uint32_t>() + first_main_draw,
                            (uint32_t)n_main_draws, n_main_tris, c->d_pair_count.as<uint32_t>() + main_first_instance,
-                           c->batch_instances - main_first_instance, c->d_counters.as<uint32_t>(), tris_main);
+                           c->batch_instances - main_first_instance, frame_counters(c), tris_main);
         if (have_blend)
             launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_blend_draw,
                                c->d_first_tri.as<uint32_t>() + first_blend_draw, (uint32_t)n_blend_draws, n_blend_tris,
                                c->d_pair_count.as<uint32_t>() + blend_first_instance, c->batch_instances - blend_first_instance,
-                               c->d_counters.as<uint32_t>(), tris_blend);
+                               frame_counters(c), tris_blend);
         return RDR_OK;
     };
     int cur = 0;
@@ -1411,6 +1413,8 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
 
     // ---- opaque shading + skybox
     if (S == 4 && have_blend) HIP_TRY(c->d_samples.ensure(n * 4 * 8));
+    // the previous frame's tail, on the second stream, reads the colour image until its last event
+    if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sets[c->slot ^ 1][5], 0));
     launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
                         (S == 4 && have_blend) ? c->d_samples.p : nullptr, c->d_tile_start.as<uint32_t>() + blend_tile_base,
                         c->d_tile_end.as<uint32_t>() + blend_tile_base, W, H);
@@ -1432,7 +1436,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
                             c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
                             c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p, c->d_frag_col.p,
-                            c->d_frag_head.as<uint32_t>(), c->d_counters.as<uint32_t>() + RDR_COUNTER_FRAGS, (uint32_t)capacity);
+                            c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, (uint32_t)capacity);
         HIP_TRY(hipGetLastError());
     }
 
@@ -1441,21 +1445,31 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     const float exposure = compute_exposure(c, fp);
     // a device destination receives the frame straight from the tonemap kernel (its 8-byte stores need the alignment)
     uint32_t* direct_out = (out_rgba8 && out_is_device && ((uintptr_t)out_rgba8 & 7u) == 0) ? (uint32_t*)out_rgba8 : nullptr;
-    enqueue_post(c, exposure, direct_out);
+    // The tail of the frame (bloom chain, tonemap, luminance, read-backs) goes to the second stream, behind the colour
+    // image: its small kernels then run beside the first, equally thin kernels of the next frame's geometry phase.
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    enqueue_post(c, c->stream2, exposure, direct_out);
     HIP_TRY(hipGetLastError());
     c->have_frame = true;
     c->stats.exposure = exposure;
     HIP_TRY(c->h_read.ensure(RDR_READ_BYTES));
     // the average luminance (word RDR_COUNTER_LUM) and the spread counters, one copy
-    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES, c->d_counters.p, RDR_COUNTER_BYTES,
-                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES, frame_counters(c), RDR_COUNTER_BYTES,
+                           hipMemcpyDeviceToHost, c->stream2));
     if (out_rgba8 && !direct_out)
-        HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+        HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream2));
+    HIP_TRY(hipEventRecord(c->ev[5], c->stream2));
     c->pending[c->slot].on = true;
     c->pending[c->slot].host = c->stats;
-    // With a device destination the call only enqueues; rdr_synchronize(), or the next frame once its own triangle
-    // set-up has run, picks up the luminance and the counters.
+    // The frame before this one has had the whole set-up of this one to finish its tail: its results are picked up
+    // now, so that it is complete (image, luminance, counters) when this call returns.
+    if (c->pending[c->slot ^ 1].on) {
+        HIP_TRY(hipEventSynchronize(c->ev_sets[c->slot ^ 1][5]));
+        harvest(c, c->slot ^ 1);
+    }
+    // With a device destination the call only enqueues; rdr_synchronize(), or the next frame, picks up the luminance
+    // and the counters.
     if (out_is_device && out_rgba8) return RDR_OK;
     RDR_TRY(rdr_synchronize(c));
     if (out_avg) *out_avg = c->last_avg_log_lum;
@@ -1466,6 +1480,7 @@ int rdr_synchronize(rdr_ctx* c) {
     if (!c) return RDR_ERR_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
     harvest(c, c->slot ^ 1);  // the older frame first, so that done_stats ends up holding the newest
     harvest(c, c->slot);
     return RDR_OK;
@@ -1480,6 +1495,7 @@ int rdr_get_frame_stats(rdr_ctx* c, rdr_frame_stats* out) {
 static int read_back(rdr_ctx* c, void* dst, const void* src, size_t bytes) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return RDR_OK;
 }
@@ -1577,11 +1593,11 @@ int rdr_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_
     }
     HIP_TRY(hipMemcpyAsync(c->d_hdr.p, h16.data(), n * 8, hipMemcpyHostToDevice, c->stream));
     for (int i = 0; i < 10; i++) HIP_TRY(hipEventRecord(c->ev[i], c->stream));
-    enqueue_post(c, exposure);
+    enqueue_post(c, c->stream, exposure);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, c->d_out.p, n * 4, hipMemcpyDeviceToHost));
-    if (out_avg) HIP_TRY(hipMemcpy(out_avg, c->d_counters.as<float>() + RDR_COUNTER_LUM, 4, hipMemcpyDeviceToHost));
+    if (out_avg) HIP_TRY(hipMemcpy(out_avg, (float*)frame_counters(c) + RDR_COUNTER_LUM, 4, hipMemcpyDeviceToHost));
     return RDR_OK;
 }
 
