@@ -188,6 +188,16 @@ struct rdr_ctx {
     // GPU's issue slots (their tiles mostly wait): the 4x one runs on a second stream beside the other.
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Geometry and shading of consecutive frames overlap: `stream` carries the geometry phase of a frame (set-up, binning,
+    // sort, rasterisers; `stream3` takes the 4x rasteriser beside the shadow-view one), `stream2` its shading, blended
+    // pass and tail. What the geometry phase writes and the shading reads exists twice (`alt` holds the set of the
+    // other frame slot; the two are swapped at the start of every frame), so the geometry phase of frame k+1 runs
+    // while frame k is shaded. The point-light shadow maps exist once (a face nothing moves in keeps what it held):
+    // their rasteriser launch waits for the previous frame's shading (ev_shaded).
+    hipStream_t stream3 = nullptr;
+    hipStream_t stream4 = nullptr;  // the tail of a frame (bloom chain, tonemap, luminance, read-backs), beside the next frame's shading
+    hipEvent_t ev_shaded[2] = {nullptr, nullptr};
+    struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr; } alt;
     PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
 };
 
@@ -465,9 +475,9 @@ void harvest(rdr_ctx* c, int slot) {
     if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) st.ms_bloom = ms;
     if (hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess) st.ms_tonemap = ms;
     if (hipEventElapsedTime(&ms, ev[0], ev[5]) == hipSuccess) st.ms_total = ms;
-    // ev[1] closes the geometry phase right behind the tile rasteriser and right in front of the shading kernel; a
-    // recorded event costs the stream about 5 us, so the three roles share one
-    if (hipEventElapsedTime(&ms, ev[1], ev[7]) == hipSuccess) st.ms_shade_kernel = ms;
+    // ev[1] closes the geometry phase right behind the tile rasterisers (the shading stream waits for it); ev[6] and
+    // ev[7] bracket the shading kernel on its own stream
+    if (hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) st.ms_shade_kernel = ms;
     if (hipEventElapsedTime(&ms, ev[8], ev[1]) == hipSuccess) st.ms_raster_kernel = ms;
     c->done_stats = st;
     c->pending[slot].on = false;
@@ -575,30 +585,38 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
     if (out_cur) *out_cur = cur;
     // tile range per sample count (views are laid out in order, so each is one interval); tiles of views this
     // kernel does not rasterise (load == 2) are left out
-    RasterRange rr[2] = {{0xFFFFFFFFu, 0u, 0u}, {0xFFFFFFFFu, 0u, 0u}};
+    // three groups: single-sampled views that start from a clear (cascades, static maps), single-sampled views that
+    // start from another map (point-light faces with moving meshes), the 4x view
+    RasterRange rr[3] = {{0xFFFFFFFFu, 0u, 0u}, {0xFFFFFFFFu, 0u, 0u}, {0xFFFFFFFFu, 0u, 0u}};
     for (uint32_t vi = 0; vi < b.views.size(); vi++) {
         const DView& v = b.views[vi];
         if (v.load == 2u) continue;
-        RasterRange& r = rr[v.samples == 4 ? 1 : 0];
+        RasterRange& r = rr[v.samples == 4 ? 2 : (v.load == 1u ? 1 : 0)];
         if (r.first_tile == 0xFFFFFFFFu) { r.first_tile = v.tile_base; r.first_view = vi; }
         r.end_tile = v.tile_base + v.tiles_x * v.tiles_y;
     }
     HIP_TRY(hipEventRecord(c->ev[8], c->stream));
     const RasterRange none = {0xFFFFFFFFu, 0u, 0u};
-    const bool both = rr[0].first_tile < rr[0].end_tile && rr[1].first_tile < rr[1].end_tile;
-    if (both) {
+    auto launch = [&](hipStream_t st, const RasterRange& s1, const RasterRange& s4) {
+        launch_raster(st, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s1, s4);
+    };
+    const bool side = rr[2].first_tile < rr[2].end_tile && (rr[0].first_tile < rr[0].end_tile || rr[1].first_tile < rr[1].end_tile);
+    if (side) {
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        launch_raster(c->stream2, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), none, rr[1]);
-        HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
-        launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), rr[0], none);
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+        launch(c->stream3, none, rr[2]);
+        HIP_TRY(hipEventRecord(c->ev_join, c->stream3));
     } else {
-        launch_raster(c->stream, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), rr[0], rr[1]);
+        launch(c->stream, none, rr[2]);
     }
+    launch(c->stream, rr[0], none);
+    if (rr[1].first_tile < rr[1].end_tile) {
+        // the point-light shadow maps exist once: the previous frame's shading may still be reading them
+        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[c->slot ^ 1], 0));
+        launch(c->stream, rr[1], none);
+    }
+    if (side) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     HIP_TRY(hipGetLastError());
     return RDR_OK;
 }
@@ -672,6 +690,7 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
     }
     if (!sb.views.empty()) {
         RDR_TRY(raster_batch(c, sb));
+        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[c->slot ^ 1], 0));  // see raster_batch
         for (uint32_t i : refreshed) {
             const size_t off = (size_t)c->lights[i].slot * 6 * face_px;
             HIP_TRY(hipMemcpyAsync(c->d_point_shadow.as<float>() + off, c->d_point_static.as<float>() + off, 6 * face_px * 4,
@@ -829,6 +848,8 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     ok = ok && hipStreamCreate(&c->stream2) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreate(&c->stream3) == hipSuccess && hipStreamCreate(&c->stream4) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_shaded[i], hipEventDisableTiming) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
     std::vector<float> tables(768);
     for (int i = 0; i < 256; i++) {
@@ -862,6 +883,8 @@ void rdr_destroy(rdr_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+    if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     DevBuf* bufs[] = {&c->d_pos, &c->d_attr, &c->d_idx, &c->d_prims, &c->d_textures, &c->d_tables, &c->d_trig, &c->d_env,
                       &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
@@ -869,12 +892,18 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_counters, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
+    DevBuf* alts[] = {&c->alt.batch_tables, &c->alt.frame, &c->alt.shade_tris, &c->alt.recs, &c->alt.keys[0], &c->alt.keys[1], &c->alt.vals[0],
+                      &c->alt.vals[1], &c->alt.tile_start, &c->alt.depth, &c->alt.vis, &c->alt.dir_shadow, &c->alt.hdr};
+    for (DevBuf* b : alts) b->release();
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
     for (int i = 0; i < 20; i++) if (c->ev_sets[i / 10][i % 10]) (void)hipEventDestroy(c->ev_sets[i / 10][i % 10]);
     if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 0; i < 2; i++) if (c->ev_shaded[i]) (void)hipEventDestroy(c->ev_shaded[i]);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     c->h_frame.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1296,14 +1325,22 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     RDR_TRY(upload_scene(c));
     RDR_TRY(run_skinning(c));
     RDR_TRY(ensure_post_targets(c));
-    HIP_TRY(c->d_depth.ensure(n * S * 4));
-    HIP_TRY(c->d_vis.ensure(n * S * 4));
     c->slot = (int)(c->frames & 1u);
     c->ev = c->ev_sets[c->slot];
     if (c->pending[c->slot].on) {  // the frame before the previous one was never picked up: it has long finished
         HIP_TRY(hipEventSynchronize(c->ev[5]));
         harvest(c, c->slot);
     }
+    {   // this frame's geometry phase writes the set the frame before the previous one used
+        rdr_ctx::AltBuffers& o = c->alt;
+        std::swap(c->d_batch_tables, o.batch_tables); std::swap(c->d_frame, o.frame); std::swap(c->d_shade_tris, o.shade_tris);
+        std::swap(c->d_recs, o.recs); std::swap(c->d_tile_start, o.tile_start); std::swap(c->d_depth, o.depth); std::swap(c->d_vis, o.vis);
+        std::swap(c->d_dir_shadow, o.dir_shadow); std::swap(c->d_hdr, o.hdr);
+        for (int k = 0; k < 2; k++) { std::swap(c->d_keys[k], o.keys[k]); std::swap(c->d_vals[k], o.vals[k]); }
+    }
+    HIP_TRY(c->d_depth.ensure(n * S * 4));
+    HIP_TRY(c->d_vis.ensure(n * S * 4));
+    HIP_TRY(c->d_hdr.ensure(n * 8));
     c->stats = rdr_frame_stats{};
     c->stats.frame_index = ++c->frames;
     HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_BYTES, c->stream));
@@ -1413,12 +1450,14 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
 
     // ---- opaque shading + skybox
     if (S == 4 && have_blend) HIP_TRY(c->d_samples.ensure(n * 4 * 8));
-    // the previous frame's tail, on the second stream, reads the colour image until its last event
-    if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_sets[c->slot ^ 1][5], 0));
-    launch_shade_opaque(c->stream, (int)S, c->d_frame.as<DFrame>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
+    // from here on the frame runs on the shading stream, behind its own geometry phase (ev[1]) and, in stream order,
+    // behind the previous frame's shading and tail
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev[1], 0));
+    HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
+    launch_shade_opaque(c->stream2, (int)S, c->d_frame.as<DFrame>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
                         (S == 4 && have_blend) ? c->d_samples.p : nullptr, c->d_tile_start.as<uint32_t>() + blend_tile_base,
                         c->d_tile_end.as<uint32_t>() + blend_tile_base, W, H);
-    HIP_TRY(hipEventRecord(c->ev[7], c->stream));
+    HIP_TRY(hipEventRecord(c->ev[7], c->stream2));
     HIP_TRY(hipGetLastError());
 
     // ---- blended draws, back to front; resolves its tiles into hdr
@@ -1433,7 +1472,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         HIP_TRY(c->d_frags.ensure(capacity * 16));
         HIP_TRY(c->d_frag_col.ensure(capacity * 16));
         HIP_TRY(c->d_frag_head.ensure(n * 4));
-        launch_raster_blend(c->stream, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
+        launch_raster_blend(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
                             c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
                             c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p, c->d_frag_col.p,
                             c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, (uint32_t)capacity);
@@ -1445,21 +1484,19 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     const float exposure = compute_exposure(c, fp);
     // a device destination receives the frame straight from the tonemap kernel (its 8-byte stores need the alignment)
     uint32_t* direct_out = (out_rgba8 && out_is_device && ((uintptr_t)out_rgba8 & 7u) == 0) ? (uint32_t*)out_rgba8 : nullptr;
-    // The tail of the frame (bloom chain, tonemap, luminance, read-backs) goes to the second stream, behind the colour
-    // image: its small kernels then run beside the first, equally thin kernels of the next frame's geometry phase.
-    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    enqueue_post(c, c->stream2, exposure, direct_out);
+    HIP_TRY(hipEventRecord(c->ev_shaded[c->slot], c->stream2));  // the shadow maps and the geometry phase's outputs have been read
+    HIP_TRY(hipStreamWaitEvent(c->stream4, c->ev_shaded[c->slot], 0));  // the tail has its own stream: the next frame's shading does not queue behind it
+    enqueue_post(c, c->stream4, exposure, direct_out);
     HIP_TRY(hipGetLastError());
     c->have_frame = true;
     c->stats.exposure = exposure;
     HIP_TRY(c->h_read.ensure(RDR_READ_BYTES));
     // the average luminance (word RDR_COUNTER_LUM) and the spread counters, one copy
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES, frame_counters(c), RDR_COUNTER_BYTES,
-                           hipMemcpyDeviceToHost, c->stream2));
+                           hipMemcpyDeviceToHost, c->stream4));
     if (out_rgba8 && !direct_out)
-        HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream2));
-    HIP_TRY(hipEventRecord(c->ev[5], c->stream2));
+        HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream4));
+    HIP_TRY(hipEventRecord(c->ev[5], c->stream4));
     c->pending[c->slot].on = true;
     c->pending[c->slot].host = c->stats;
     // The frame before this one has had the whole set-up of this one to finish its tail: its results are picked up
@@ -1480,7 +1517,9 @@ int rdr_synchronize(rdr_ctx* c) {
     if (!c) return RDR_ERR_INVALID;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream3));
     HIP_TRY(hipStreamSynchronize(c->stream2));
+    HIP_TRY(hipStreamSynchronize(c->stream4));
     harvest(c, c->slot ^ 1);  // the older frame first, so that done_stats ends up holding the newest
     harvest(c, c->slot);
     return RDR_OK;
@@ -1495,7 +1534,9 @@ int rdr_get_frame_stats(rdr_ctx* c, rdr_frame_stats* out) {
 static int read_back(rdr_ctx* c, void* dst, const void* src, size_t bytes) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream3));
     HIP_TRY(hipStreamSynchronize(c->stream2));
+    HIP_TRY(hipStreamSynchronize(c->stream4));
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return RDR_OK;
 }
