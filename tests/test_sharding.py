@@ -157,3 +157,53 @@ def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi, exposure_
         assert piped_stats[k][1:] == serial_stats[k][1:], f"counters of frame {k}"
         assert piped_stats[k][0] == serial_stats[k][0] == lum[k], f"luminance of frame {k}"
         assert piped_stats[k][3] == k + 1
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_with_changing_scene_state(hip_capi):
+    """Between frames that are still in flight the caller moves the camera, a dynamic mesh and the lights, and now and
+    then asks for a frame in host memory (which drains the pipeline). Every frame must equal the same frame rendered by
+    a second context one frame at a time: nothing a frame reads may be overwritten by the frame enqueued behind it."""
+    import torch
+
+    from renderer_amd import scenes
+    from renderer_amd.api import Renderer, default_settings
+
+    W, H, n = 160, 96, 9
+
+    def build():
+        r = Renderer(hip_capi, W, H, default_settings(msaa=4, directional_shadow_map_resolution=256, point_shadow_map_resolution=64))
+        ids = scenes.small_scene(r)
+        return r, ids
+
+    def set_state(r, ids, k):
+        r.set_camera(position=(0.25 * k - 0.8, 1.1 + 0.05 * k, 4.2 - 0.15 * k), euler=(-0.08, 0.04 * k, 0.0))
+        m = scenes.translation(0.4 * np.sin(0.9 * k), 0.9 + 0.08 * k, 0.4 - 0.1 * k)
+        r.set_mesh_transform(ids["sphere"], m.T)
+        r.set_lights([((1.5 - 0.2 * k, 2.2, 1.0 + 0.1 * k), (20.0 + 3 * k, 18.0, 14.0), True),
+                      ((-1.0, 1.5 + 0.1 * k, 2.0), (6.0, 9.0 + k, 12.0), k % 2 == 0)], scenes.default_directional_light())
+
+    params = dict(exposure_mode=1, temporal_luminance=0.4)
+    r1, ids1 = build()
+    serial = []
+    for k in range(n):
+        set_state(r1, ids1, k)
+        img, _ = r1.render_frame(**params)
+        serial.append(img.copy())
+    r1.close()
+
+    r2, ids2 = build()
+    slots = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(n)]
+    host = {}
+    for k in range(n):
+        set_state(r2, ids2, k)
+        if k % 4 == 3:
+            host[k], _ = r2.render_frame(**params)
+        else:
+            r2.render_frame(device_ptr=slots[k].data_ptr(), **params)
+    r2.synchronize()
+    assert r2.frame_stats().frame_index == n
+    for k in range(n):
+        got = host[k] if k in host else slots[k].cpu().numpy()
+        assert np.array_equal(got, serial[k]), f"frame {k}"
+    r2.close()
