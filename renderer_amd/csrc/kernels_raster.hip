@@ -363,17 +363,61 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
     }
 }
 
-// One thread per candidate pair. pair_offset is the exclusive scan of pair_count.
+// Largest i in [0, n) with offset[i] <= p (offset[0] <= p), found by a whole wave: 64 probes per round, so a million
+// entries take four dependent rounds of loads where a binary search takes twenty.
+RDR_DEV uint32_t wave_upper_index(const uint32_t* __restrict__ offset, uint32_t n, uint32_t p, uint32_t lane) {
+    uint32_t a = 0, len = n;
+    while (len > 1u) {
+        const uint32_t step = (len + 63u) >> 6;
+        const uint32_t i = a + lane * step;
+        const bool le = lane * step < len && offset[i] <= p;   // true for a prefix of the lanes: the offsets are sorted
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(le));  // >= 1: lane 0 probes offset[a]
+        const uint32_t adv = (cnt - 1u) * step;
+        a += adv;
+        len = min(step, len - adv);
+    }
+    return a;
+}
+
+// One thread per candidate pair: pair p belongs to the triangle instance i with pair_offset[i] <= p < pair_offset[i + 1]
+// (pair_offset = exclusive scan of pair_count) and is that triangle's (p - pair_offset[i])-th tile. The owners of the
+// 256 pairs of a block are a run of instances: two waves find its ends with the wave-wide search, the block copies
+// that run of offsets to LDS and every thread finds its owner there. (Runs longer than EMIT_SPAN - stretches of
+// instances without pairs - are searched in global memory, between the two ends.) The chain of dependent loads per
+// pair is 5 long instead of 20, which matters most when this kernel runs beside the previous frame's shading.
+#define EMIT_SPAN 2048u
 __global__ void __launch_bounds__(256) k_emit(const DView* __restrict__ views, const DTriRec* __restrict__ recs,
                                               const uint32_t* __restrict__ pair_offset, uint32_t n_inst, uint32_t n_pairs,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n_pairs) return;
-    uint32_t lo = 0, hi = n_inst;  // largest i with pair_offset[i] <= p
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (pair_offset[mid] <= p) lo = mid; else hi = mid;
+    __shared__ uint32_t lds_off[EMIT_SPAN];
+    __shared__ uint32_t lds_end[2];
+    const uint32_t p0 = blockIdx.x * 256u, p = p0 + threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (wave < 2u) {
+        const uint32_t target = wave == 0u ? p0 : min(p0 + 255u, n_pairs - 1u);
+        const uint32_t e = wave_upper_index(pair_offset, n_inst, target, lane);
+        if (lane == 0u) lds_end[wave] = e;
     }
+    __syncthreads();
+    const uint32_t first = lds_end[0], span = lds_end[1] - first + 1u;
+    const bool in_lds = span <= EMIT_SPAN;
+    if (in_lds)
+        for (uint32_t i = threadIdx.x; i < span; i += 256u) lds_off[i] = pair_offset[first + i];
+    __syncthreads();
+    if (p >= n_pairs) return;
+    uint32_t lo = 0, hi = span;  // largest i in the run with offset <= p
+    if (in_lds) {
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (lds_off[mid] <= p) lo = mid; else hi = mid;
+        }
+    } else {
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pair_offset[first + mid] <= p) lo = mid; else hi = mid;
+        }
+    }
+    lo += first;
     const DTriRec& r = recs[lo];
     const uint32_t local = p - pair_offset[lo];
     const int n = (int)(r.n_view & 255u);
