@@ -122,3 +122,88 @@ def test_full_size_properties_4k(hip_capi):
     d, _ = r.render_frame(exposure_mode=2, exposure=e)
     assert np.array_equal(c, d)
     r.close()
+
+
+def test_config5_full_size_ten_million_triangles(hip_capi):
+    """Config 5 at its full size: a 9 999 392-triangle displaced grid (one primitive) from 8 orbit views at
+    3840x2160 with 4x MSAA and 4 cascades. The CPU checker would need minutes per view, so the views are held to the
+    size-independent properties: a sample is covered exactly when its depth was written, depth stays in [0, 1], the
+    counters add up (every view submits the grid once per cascade that sees it plus once for the main view), each view
+    differs from the others, and rendering a view again gives the same bytes, depth and counters."""
+    W, H = 3840, 2160
+    r = Renderer(hip_capi, W, H, default_settings(msaa=4))
+    info = scenes.raster_stress(r, quads_per_side=2236)
+    assert info["triangles"] == 2 * 2236 * 2236
+    frames, stats = [], []
+    for k in range(8):
+        scenes.orbit_camera(r, k)
+        out, _ = r.render_frame(**FRAME)
+        s = r.frame_stats()
+        stats.append((int(s.triangle_instances), int(s.triangles_binned), int(s.tile_pairs), int(s.views)))
+        assert s.triangle_instances % info["triangles"] == 0 and 2 <= s.triangle_instances // info["triangles"] <= 5
+        assert 0 < s.triangles_binned < s.triangle_instances and s.tile_pairs >= s.triangles_binned
+        depth, vis = r.read_depth(), r.read_visibility()
+        assert np.array_equal(vis == 0xFFFFFFFF, depth >= 1.0), f"view {k}: coverage and depth disagree"
+        assert depth.min() >= 0.0 and depth.max() <= 1.0
+        assert vis[vis != 0xFFFFFFFF].max() < info["triangles"]
+        assert (vis[0] != 0xFFFFFFFF).mean() > 0.3, f"view {k}: the grid fills a good part of the frame"
+        assert out[..., :3].std() > 5
+        frames.append(out.copy())
+        if k in (0, 5):
+            keep_depth, keep_vis = depth, vis
+            again, _ = r.render_frame(**FRAME)
+            s2 = r.frame_stats()
+            assert np.array_equal(again, frames[k]), f"view {k} is not reproducible"
+            assert np.array_equal(r.read_depth(), keep_depth) and np.array_equal(r.read_visibility(), keep_vis)
+            assert (int(s2.triangle_instances), int(s2.triangles_binned), int(s2.tile_pairs), int(s2.views)) == stats[k]
+    assert len({f.tobytes() for f in frames}) == 8
+    r.close()
+
+
+def test_config3_animation_batch_1080p(hip_capi):
+    """Config 3 at 1920x1080 with 4x MSAA on one GPU: 32 frames (t_k = k / 30 s) of the hall at half detail with two
+    skinned, key-framed figures, rendered through the frame sharder with two frames in flight. The whole batch is
+    rendered twice: every frame must come out the same both times (replay determinism), differ from its neighbours,
+    and three frames rendered on their own, to completion, by a second context must equal the batch's."""
+    import torch
+
+    from renderer_amd.sharding import FrameSharder
+
+    W, H, n = 1920, 1080, 32
+
+    def build():
+        r = Renderer(hip_capi, W, H, default_settings(msaa=4))
+        scenes.sponza_like(r, tex_size=256, env_res=64, detail=0.5)
+        figs = [scenes.SkinnedFigure(r, n_bones=16, length=3.2, radius=0.3, nu=64, nv=256, tex_size=128, origin=o, seed=61 + i)
+                for i, o in enumerate(((-6.0, 0.0, 0.5), (-3.0, 0.0, -1.0)))]
+        return r, figs
+
+    def set_frame_for(figs):
+        def set_frame(rr, k):
+            rr.set_camera(position=(-11.0 + 0.05 * k, 2.2, 0.6), euler=(-0.05, -1.45 + 0.004 * k, 0.0))
+            for f in figs:
+                f.pose(k / 30.0)
+        return set_frame
+
+    r, figs = build()
+    sharder = FrameSharder(r, dist=None, device="cuda:0", depth=2)
+    params = dict(exposure_mode=1, temporal_luminance=0.5)
+    runs = []
+    for _ in range(2):
+        got = {}
+        lum = sharder.run(n, set_frame_for(figs), params, on_frame=lambda k, t: got.__setitem__(k, t.cpu().numpy().copy()))
+        torch.cuda.synchronize()
+        assert sorted(got) == list(range(n)) and sorted(lum) == list(range(n))
+        runs.append((got, lum))
+    for k in range(n):
+        assert np.array_equal(runs[0][0][k], runs[1][0][k]), f"frame {k} differs between two runs of the batch"
+        assert runs[0][1][k] == runs[1][1][k]
+    assert len({runs[0][0][k].tobytes() for k in range(n)}) == n
+    r.close()
+    r2, figs2 = build()
+    for k in (0, 13, 31):
+        set_frame_for(figs2)(r2, k)
+        img, avg = r2.render_frame(**params)
+        assert np.array_equal(img, runs[0][0][k]), f"frame {k} rendered alone differs from the batch"
+        assert avg == runs[0][1][k]
+    r2.close()

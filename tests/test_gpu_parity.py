@@ -175,3 +175,57 @@ def test_chunk_culling_changes_nothing(orc_capi, hip_capi, msaa):
         assert so.chunks_culled == 0 and sh.chunks_culled > 0
         hp.assert_image_close(out_o, out_h)
     assert (rh.read_depth() < 1.0).any()
+
+
+@pytest.mark.parametrize("size", [(64, 64), (32, 8), (1, 1), (37, 21), (100, 3), (5, 250), (257, 129)])
+def test_mip_chain_parity(orc_capi, hip_capi, size):
+    """loadImage builds the chain by successive LINEAR blits (VulkanRenderer.cpp:311-346): every level of an sRGB and
+    of a UNORM image, square and ragged sizes (odd sizes take the general blit weights, not the 2x2 box), three-channel
+    input included, must come out bit for bit as the CPU restatement stores them."""
+    w, h = size
+    ro, rh = hp.make_pair(orc_capi, hip_capi, 16, 16)
+    rng = np.random.default_rng(w * 1000 + h)
+    n_levels = int(np.floor(np.log2(max(w, h)))) + 1
+    for fmt, ch in ((scenes.B.FORMAT_R8G8B8A8_SRGB, 4), (scenes.B.FORMAT_R8G8B8A8_UNORM, 4), (scenes.B.FORMAT_R8G8B8_SRGB, 3),
+                    (scenes.B.FORMAT_R8G8B8_UNORM, 3)):
+        img = rng.integers(0, 256, size=(h, w, ch), dtype=np.uint8)
+        io, ih = ro.load_image(img, fmt), rh.load_image(img, fmt)
+        for level in range(n_levels):
+            lo, lh = ro.read_image_level(io, level), rh.read_image_level(ih, level)
+            assert lo.shape == (max(1, h >> level), max(1, w >> level), 4)
+            assert np.array_equal(lo, lh), f"format {fmt} level {level} of {w}x{h}"
+        with pytest.raises(Exception):
+            rh.read_image_level(ih, n_levels)
+    # max_mip_levels cuts the chain short
+    img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    io, ih = ro.load_image(img, scenes.B.FORMAT_R8G8B8A8_UNORM, max_mip_levels=2), rh.load_image(img, scenes.B.FORMAT_R8G8B8A8_UNORM, max_mip_levels=2)
+    for level in range(min(2, n_levels)):
+        assert np.array_equal(ro.read_image_level(io, level), rh.read_image_level(ih, level))
+    with pytest.raises(Exception):
+        rh.read_image_level(ih, min(2, n_levels))
+
+
+def test_exposure_recurrence_parity(orc_capi, hip_capi):
+    """exposure_mode 0 (VulkanRenderer.cpp:1075-1082): the exposure of a frame follows from the average log-luminance
+    of the frame before it and the time step. Six frames with a moving camera and uneven time steps on both back
+    ends: the exposure pushed to the tonemap pass, the luminance fed back and the 8-bit frames must agree."""
+    W, H = 320, 280  # the luminance reduction reads a 256x256 window
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, **hp.small_settings(4))
+    scenes.small_scene(ro)
+    scenes.small_scene(rh)
+    steps = [1 / 60, 1 / 30, 0.5, 1 / 60, 2.0, 0.1]
+    exposures = []
+    for k, dt in enumerate(steps):
+        for r in (ro, rh):
+            r.set_camera(position=(0.4 + 0.25 * k, 1.7, 5.2 - 0.3 * k), euler=(-0.2, 0.05 + 0.04 * k, 0.0))
+        out_o, avg_o = ro.render_frame(exposure_mode=0, delta_time=dt)
+        out_h, avg_h = rh.render_frame(exposure_mode=0, delta_time=dt)
+        eo, eh = ro.frame_stats().exposure, rh.frame_stats().exposure
+        assert abs(eo - eh) <= 2e-4 * abs(eo), f"frame {k}: exposure {eo} vs {eh}"
+        assert abs(avg_o - avg_h) < 1e-3, f"frame {k}"
+        hp.assert_image_close(out_o, out_h)
+        exposures.append(eo)
+    # first frame: the read-back holds 0, so the adapted luminance moves from 0 towards 2^0 by 1 - e^-dt; later frames adapt
+    tl = 1.0 - np.exp(-steps[0])
+    assert abs(exposures[0] - 0.18 / (1.03 - 2.0 / (np.log2(tl + 1.0) + 2.0))) < 1e-3
+    assert len({round(e, 4) for e in exposures}) == len(exposures)
