@@ -357,6 +357,23 @@ int rdr_read_image_level(rdr_ctx* ctx, uint32_t image, uint32_t level, uint8_t* 
 int rdr_post_process(rdr_ctx* ctx, const float* hdr_rgba_f32, float exposure, uint8_t* out_rgba8,
                      float* out_avg_log_luminance);
 
+/* No counterpart in the reference. A variant of rdr_post_process for callers that cannot allocate device memory:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc. It calls no hipMalloc, hipFree
+ * or other allocating routine: the bloom chain, the log-luminance image and the partial means of the luminance
+ * reduction live in a fixed array inside the library's code object (about 21 MB per GPU, held until the process
+ * ends), which is why the image is limited to RDR_NOALLOC_MAX_PIXELS pixels (RDR_ERR_CAPACITY beyond that).
+ *   hdr_rgba16f_device  width*height RGBA16F pixels in device memory, 16-byte aligned (the colour attachment as is)
+ *   out_rgba8_device    width*height RGBA8 pixels in device memory, 8-byte aligned
+ *   out_avg_device      one float in device memory: the average log-luminance of the centre 256x256 window
+ *   stream              a hipStream_t, or NULL for the context's own stream
+ * The call only enqueues on `stream` (synchronise that stream, or call rdr_synchronize when it is NULL); width and
+ * height need not be the context's. Gamma is the context's setting. All calls on one GPU share the array, which keeps
+ * the contents of the last call: calls that overlap in time on one GPU (two streams, two contexts, two threads) race.
+ * Results are bit for bit those of rdr_post_process on the same image. */
+#define RDR_NOALLOC_MAX_PIXELS (1920u * 1088u)
+int rdr_post_process_noalloc(rdr_ctx* ctx, const void* hdr_rgba16f_device, uint32_t width, uint32_t height, float exposure,
+                             uint8_t* out_rgba8_device, float* out_avg_device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

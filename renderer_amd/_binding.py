@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 
 RDR_OK = 0
+RDR_ERR_INVALID, RDR_ERR_DEVICE, RDR_ERR_CAPACITY, RDR_ERR_UNSUPPORTED = 1, 2, 3, 4
 INVALID_ID = 0xFFFFFFFF
 
 # enum rdr_image_format (Renderer/Image.h:5-14)
@@ -127,6 +128,12 @@ SIGNATURES = {
     "post_process": (C.c_int, [_VP, _FP, C.c_float, _U8P, _FP]),
 }
 
+# entry points only the HIP library has (the CPU checker allocates nothing on a device to begin with)
+HIP_ONLY_SIGNATURES = {
+    "post_process_noalloc": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_float, _VP, _VP, _VP]),
+}
+NOALLOC_MAX_PIXELS = 1920 * 1088
+
 
 class CApi:
     """All entry points of include/rdr.h, bound from `lib` under `prefix`."""
@@ -140,6 +147,12 @@ class CApi:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
+        if prefix == "rdr_":
+            for name, (res, args) in HIP_ONLY_SIGNATURES.items():
+                fn = getattr(self.lib, prefix + name)
+                fn.restype = res
+                fn.argtypes = args
+                setattr(self, name, fn)
 
 
 def fptr(a):

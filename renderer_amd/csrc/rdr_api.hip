@@ -110,6 +110,14 @@ struct Batch {
     std::vector<DDraw> draws;
 };
 
+// Scratch of rdr_post_process_noalloc: bloom mips 0..5, the log-luminance image and the 16x16 partial means of the
+// luminance reduction for an image of at most RDR_NOALLOC_MAX_PIXELS pixels. Every GPU the library is used on holds
+// its own copy of this array from the moment the code object is loaded until the process ends. In host code the
+// name only stands for the symbol: the address on a device comes from hipGetSymbolAddress (rdr_create).
+#define NOALLOC_BLOOM_WORDS (RDR_NOALLOC_MAX_PIXELS + RDR_NOALLOC_MAX_PIXELS / 2u)  // sum of the six mips < 4/3 of mip 0; ragged sizes round down
+#define NOALLOC_SCRATCH_BYTES ((size_t)(NOALLOC_BLOOM_WORDS + RDR_NOALLOC_MAX_PIXELS + 512u) * 4u)
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 }  // namespace
 
 struct rdr_ctx {
@@ -199,6 +207,7 @@ struct rdr_ctx {
     hipEvent_t ev_shaded[2] = {nullptr, nullptr};
     struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr; } alt;
     PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
+    unsigned char* noalloc_scratch = nullptr;  // address of `scratch` on this context's device
 };
 
 namespace {
@@ -860,6 +869,8 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     ok = ok && c->d_tables.ensure(768 * 4) == hipSuccess && hipMemcpy(c->d_tables.p, tables.data(), 768 * 4, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && c->d_counters.ensure(2 * RDR_COUNTER_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, 2 * RDR_COUNTER_BYTES) == hipSuccess;
     ok = ok && c->d_frame.ensure(sizeof(DFrame) + 64) == hipSuccess;
+    // this device's copy of the no-allocation scratch array (the device is current: hipSetDevice above)
+    ok = ok && hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch)) == hipSuccess && c->noalloc_scratch != nullptr;
     if (!ok) { rdr_destroy(c); return RDR_ERR_DEVICE; }
     c->camera.type = 0;  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
     c->camera.position = make3(0, 0, 0); c->camera.euler = make3(0, 0, 0);
@@ -1639,6 +1650,43 @@ int rdr_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, c->d_out.p, n * 4, hipMemcpyDeviceToHost));
     if (out_avg) HIP_TRY(hipMemcpy(out_avg, (float*)frame_counters(c) + RDR_COUNTER_LUM, 4, hipMemcpyDeviceToHost));
+    return RDR_OK;
+}
+
+int rdr_post_process_noalloc(rdr_ctx* c, const void* hdr_rgba16f, uint32_t width, uint32_t height, float exposure, uint8_t* out_rgba8,
+                             float* out_avg, void* stream) {
+    if (!c || !hdr_rgba16f || !out_rgba8 || !out_avg) return fail(c, RDR_ERR_INVALID, "post_process_noalloc: null argument");
+    if (width == 0 || height == 0) return fail(c, RDR_ERR_INVALID, "post_process_noalloc: empty image");
+    if ((uint64_t)width * height > RDR_NOALLOC_MAX_PIXELS)
+        return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: more than RDR_NOALLOC_MAX_PIXELS pixels; use rdr_post_process");
+    if (((uintptr_t)hdr_rgba16f & 15u) || ((uintptr_t)out_rgba8 & 7u) || ((uintptr_t)out_avg & 3u))
+        return fail(c, RDR_ERR_INVALID, "post_process_noalloc: hdr must be 16-byte, out 8-byte, avg 4-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    // carve the scratch array: six bloom mips | log-luminance image | 256 + 16 partial means
+    uint32_t* bloom = (uint32_t*)c->noalloc_scratch;
+    float* loglum = (float*)(bloom + NOALLOC_BLOOM_WORDS);
+    float* lum = loglum + RDR_NOALLOC_MAX_PIXELS;
+    uint32_t off[6], bw[6], bh[6];
+    size_t words = 0;
+    for (uint32_t l = 0; l < 6; l++) {
+        bw[l] = std::max(1u, width >> l); bh[l] = std::max(1u, height >> l);
+        off[l] = (uint32_t)words;
+        words += (size_t)bw[l] * bh[l];
+    }
+    if (words > NOALLOC_BLOOM_WORDS) return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: bloom chain larger than the scratch array");
+    // the same launches, in the same order, as enqueue_post
+    for (uint32_t i = 0; i < 5; i++)
+        launch_bloom_down(st, i == 0 ? hdr_rgba16f : (const void*)(bloom + off[i]), i == 0, (int)bw[i], (int)bh[i], bloom + off[i + 1],
+                          (int)(width >> (i + 1)), (int)(height >> (i + 1)), (int)bw[i + 1]);
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t dl = 4 - i, sl = 5 - i;
+        launch_bloom_up(st, bloom + off[sl], (int)bw[sl], (int)bh[sl], bloom + off[dl], (int)(width >> dl), (int)(height >> dl), (int)bw[dl]);
+    }
+    launch_tonemap(st, hdr_rgba16f, bloom + off[1], (int)bw[1], (int)bh[1], bloom, (uint32_t*)out_rgba8, loglum, (int)width, (int)height,
+                   powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
+    launch_average_luminance(st, loglum, (int)width, (int)height, lum, out_avg);
+    HIP_TRY(hipGetLastError());
     return RDR_OK;
 }
 

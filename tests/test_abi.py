@@ -23,7 +23,8 @@ def declared_functions():
 def test_header_declares_what_the_binding_binds():
     names = declared_functions()
     assert len(names) >= 29
-    assert sorted("rdr_" + n for n in B.SIGNATURES) == names
+    assert sorted("rdr_" + n for n in list(B.SIGNATURES) + list(B.HIP_ONLY_SIGNATURES)) == names
+    assert f"#define RDR_NOALLOC_MAX_PIXELS (1920u * 1088u)" in open(HEADER).read() and B.NOALLOC_MAX_PIXELS == 1920 * 1088
 
 
 def test_hip_library_exports_every_entry_point():
