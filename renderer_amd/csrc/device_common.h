@@ -201,23 +201,27 @@ RDR_DEV int cube_face_fast(float rx, float ry, float rz, float& s, float& t) {
     t = fminf(fmaxf(fmaf(tc, hinv, 0.5f), 0.0f), 1.0f);
     return face;
 }
+// `cube` is a bordered copy (k_cube_border): the footprint at (i0, j0), i0 and j0 in [-1, r - 1], is two pairs of
+// neighbouring words, no edge handling.
 RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
     float s, t;
     const int face = cube_face_fast(dx, dy, dz, s, t);
     const uint32_t rr = cube.res >> level;
-    const int r = (int)(rr ? rr : 1u);
+    const int r = (int)(rr ? rr : 1u), pitch = r + 2;
     const RDR_GLOBAL uint32_t* px = as_global(cube.texels) + cube.level_offset[level];
     const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
     const int i0 = min(max((int)fu, -1), r - 1), j0 = min(max((int)fv, -1), r - 1);
-    uint32_t o[4];
-    cube_footprint(face, i0, j0, r, o);
+    const RDR_GLOBAL uint32_t* row = px + ((face * pitch + j0 + 1) * pitch + i0 + 1);
+    uint32_t q00, q10, q01, q11;
+    load_pair(row, q00, q10);
+    load_pair(row + pitch, q01, q11);
     float c00[3], c10[3], c01[3], c11[3];
-    unpack_r11g11b10(px[o[0]], c00[0], c00[1], c00[2]);
-    unpack_r11g11b10(px[o[1]], c10[0], c10[1], c10[2]);
-    unpack_r11g11b10(px[o[2]], c01[0], c01[1], c01[2]);
-    unpack_r11g11b10(px[o[3]], c11[0], c11[1], c11[2]);
+    unpack_r11g11b10(q00, c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(q10, c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(q01, c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(q11, c11[0], c11[1], c11[2]);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float top = fmaf(a, c10[k] - c00[k], c00[k]), bot = fmaf(a, c11[k] - c01[k], c01[k]);
@@ -313,18 +317,12 @@ RDR_DEV void tex_taps(const DTexDesc& t, const DTexture* __restrict__ table, flo
 }
 // texture geometry = size, level count, level-offset rule and wrap modes (not the sRGB bit, not the table index)
 RDR_DEV bool tex_same_geometry(const DTexDesc& x, const DTexDesc& y) {
-    return x.wh == y.wh && ((x.info ^ y.info) & (31u | (0x3Eu << 5))) == 0u;
+    return (int)(x.wh == y.wh) & (int)(((x.info ^ y.info) & (31u | (0x3Eu << 5))) == 0u);
 }
+// Bilinear filter of four raw RGBA8 texels. sRGB channels go through the decode table before filtering; UNORM
+// channels are filtered as bytes and scaled by 1/255 once afterwards.
 template <int MASK>
-RDR_DEV void tex_fetch_level(const float* srgb, const DTexDesc& t, const TexLevelTaps& k, float out[4]) {
-    const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base);
-    // the two texels of a row are neighbours in memory unless the footprint wraps around the edge
-    uint32_t q00, q10, q01, q11;
-    load_pair(px + k.o00, q00, q10);
-    load_pair(px + k.o01, q01, q11);
-    if (k.o10 != k.o00 + 1u) { q10 = px[k.o10]; q11 = px[k.o11]; }
-    const bool is_srgb = ((t.info >> 5) & RDR_TEXD_SRGB) != 0u;
-    const float a = k.a, b = k.b;
+RDR_DEV void tex_filter(const float* srgb, bool is_srgb, uint32_t q00, uint32_t q10, uint32_t q01, uint32_t q11, float a, float b, float out[4]) {
     float c00[4], c10[4], c01[4], c11[4];
     if (is_srgb && (MASK & 7)) {
 #pragma unroll
@@ -337,20 +335,28 @@ RDR_DEV void tex_fetch_level(const float* srgb, const DTexDesc& t, const TexLeve
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             if (!(MASK & (1 << c))) continue;
-            c00[c] = (float)((q00 >> (8 * c)) & 255u) * RDR_INV255; c10[c] = (float)((q10 >> (8 * c)) & 255u) * RDR_INV255;
-            c01[c] = (float)((q01 >> (8 * c)) & 255u) * RDR_INV255; c11[c] = (float)((q11 >> (8 * c)) & 255u) * RDR_INV255;
+            c00[c] = (float)((q00 >> (8 * c)) & 255u); c10[c] = (float)((q10 >> (8 * c)) & 255u);
+            c01[c] = (float)((q01 >> (8 * c)) & 255u); c11[c] = (float)((q11 >> (8 * c)) & 255u);
         }
     }
-    if (MASK & 8) {
-        c00[3] = (float)(q00 >> 24) * RDR_INV255; c10[3] = (float)(q10 >> 24) * RDR_INV255;
-        c01[3] = (float)(q01 >> 24) * RDR_INV255; c11[3] = (float)(q11 >> 24) * RDR_INV255;
-    }
+    if (MASK & 8) { c00[3] = (float)(q00 >> 24); c10[3] = (float)(q10 >> 24); c01[3] = (float)(q01 >> 24); c11[3] = (float)(q11 >> 24); }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         if (!(MASK & (1 << c))) continue;
         const float top = fmaf(a, c10[c] - c00[c], c00[c]), bot = fmaf(a, c11[c] - c01[c], c01[c]);
-        out[c] = fmaf(b, bot - top, top);
+        const float v = fmaf(b, bot - top, top);
+        out[c] = (c == 3 || !is_srgb) ? v * RDR_INV255 : v;
     }
+}
+template <int MASK>
+RDR_DEV void tex_fetch_level(const float* srgb, const DTexDesc& t, const TexLevelTaps& k, float out[4]) {
+    const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base);
+    // the two texels of a row are neighbours in memory unless the footprint wraps around the edge
+    uint32_t q00, q10, q01, q11;
+    load_pair(px + k.o00, q00, q10);
+    load_pair(px + k.o01, q01, q11);
+    if (k.o10 != k.o00 + 1u) { q10 = px[k.o10]; q11 = px[k.o11]; }
+    tex_filter<MASK>(srgb, ((t.info >> 5) & RDR_TEXD_SRGB) != 0u, q00, q10, q01, q11, k.a, k.b, out);
 }
 template <int MASK>
 RDR_DEV void tex_fetch(const float* srgb, const DTexDesc& t, const TexTaps& k, float out[4]) {
@@ -358,6 +364,33 @@ RDR_DEV void tex_fetch(const float* srgb, const DTexDesc& t, const TexTaps& k, f
     if (k.two) {
         float c1[4];
         tex_fetch_level<MASK>(srgb, t, k.lv[1], c1);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (MASK & (1 << c)) out[c] = fmaf(k.f, c1[c] - out[c], out[c]);
+    }
+}
+// The same fetch in two steps, so that the loads of several textures are in flight together: tex_issue only loads
+// the raw texels (the taps must have neighbouring pairs: tex_pairs_adjacent), tex_resolve filters them.
+struct TexRaw { uint32_t q[2][4]; };
+RDR_DEV bool tex_pairs_adjacent(const TexTaps& k) {
+    return (int)(k.lv[0].o10 == k.lv[0].o00 + 1u) & ((int)!k.two | (int)(k.lv[1].o10 == k.lv[1].o00 + 1u));
+}
+RDR_DEV void tex_issue(const DTexDesc& t, const TexTaps& k, TexRaw& r) {
+    const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base);
+    load_pair(px + k.lv[0].o00, r.q[0][0], r.q[0][1]);
+    load_pair(px + k.lv[0].o01, r.q[0][2], r.q[0][3]);
+    if (k.two) {
+        load_pair(px + k.lv[1].o00, r.q[1][0], r.q[1][1]);
+        load_pair(px + k.lv[1].o01, r.q[1][2], r.q[1][3]);
+    }
+}
+template <int MASK>
+RDR_DEV void tex_resolve(const float* srgb, const DTexDesc& t, const TexTaps& k, const TexRaw& r, float out[4]) {
+    const bool is_srgb = ((t.info >> 5) & RDR_TEXD_SRGB) != 0u;
+    tex_filter<MASK>(srgb, is_srgb, r.q[0][0], r.q[0][1], r.q[0][2], r.q[0][3], k.lv[0].a, k.lv[0].b, out);
+    if (k.two) {
+        float c1[4];
+        tex_filter<MASK>(srgb, is_srgb, r.q[1][0], r.q[1][1], r.q[1][2], r.q[1][3], k.lv[1].a, k.lv[1].b, c1);
 #pragma unroll
         for (int c = 0; c < 4; c++)
             if (MASK & (1 << c)) out[c] = fmaf(k.f, c1[c] - out[c], out[c]);

@@ -42,13 +42,13 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DT
 // kernels_shade.hip
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,
                         const uint32_t* pair_offset, uint32_t n_after, const uint32_t* pair_total, DShadeTri* out);
-void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
+void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H);
 // blended pass: fragment list slots are handed out in runs of RDR_FRAG_RUN; `capacity` slots exist (see blend_capacity);
 // *frag_used counts the slots handed out and must be zero when launch_raster_blend is called
 #define RDR_FRAG_RUN 128u
 #define RDR_BLEND_SHADE_BLOCKS 2048u
-void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,
+void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
                          void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity);
 
@@ -59,6 +59,11 @@ void launch_skin(hipStream_t s, const void* rest_pos, const void* rest_attr, con
 void launch_equirect_to_cube(hipStream_t s, const void* pano_rgba32f, int w, int h, uint32_t* dst, int res);
 void launch_brdf_lut(hipStream_t s, uint32_t* dst, int size, int samples, const float* trig);
 void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n);
+// point-light shadow cubes stored as n_cubes x 6 faces of (res + 2)^2: fills every face's one-texel border in place
+void launch_shadow_cube_border(hipStream_t s, float* maps, int res, uint32_t n_cubes);
+void launch_fill_f32(hipStream_t s, float* dst, float v, size_t n);
+// one level of a cube (6 x res^2 words) -> the same level with a one-texel border per face (6 x (res + 2)^2 words)
+void launch_cube_border(hipStream_t s, const uint32_t* src, uint32_t* dst, int res);
 void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb);
 void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig);
 void launch_mip_blit(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int srgb, const float* srgb_decode,

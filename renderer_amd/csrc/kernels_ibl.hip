@@ -243,6 +243,41 @@ __global__ void __launch_bounds__(256) k_brdf_lut(uint32_t* __restrict__ dst, in
     dst[idx] = float_to_unorm8(A / (float)samples) | (float_to_unorm8(B / (float)samples) << 8) | 0xFF000000u;
 }
 
+// One level of a cube with a one-texel border around every face: texel (i, j), i and j in [-1, res], of `face` sits at
+// (face * (res + 2) + j + 1) * (res + 2) + i + 1 and holds what seamless filtering reads there (the texel across the
+// shared edge; at a corner the clamped-row texel, as cube_fold resolves it). The shading kernels filter from these
+// copies: a 2x2 footprint is then always four neighbouring words, whatever face edge it touches.
+__global__ void __launch_bounds__(256) k_cube_border(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int res) {
+    const int p = res + 2;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= 6u * (uint32_t)(p * p)) return;
+    const int face = (int)(t / (uint32_t)(p * p)), rem = (int)(t % (uint32_t)(p * p));
+    dst[t] = src[cube_texel_offset(face, rem % p - 1, rem / p - 1, res)];
+}
+
+// Border of the point-light shadow cubes, in place: face `f` of cube `c` is a (res + 2)^2 image whose interior the
+// rasteriser writes; its one-texel border receives the depth across the shared cube edges (cube_fold), so that the
+// 2x2 compare footprint of a shadow look-up is four neighbouring words anywhere on the face. One thread per
+// (cube, face, side, position along the side); sources are interior texels only, so the order of threads is free.
+__global__ void __launch_bounds__(256) k_shadow_cube_border(float* __restrict__ maps, int res, uint32_t n_cubes) {
+    const int p = res + 2;
+    const uint32_t per_face = 4u * (uint32_t)p, t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_cubes * 6u * per_face) return;
+    const uint32_t cube = t / (6u * per_face), rem = t % (6u * per_face);
+    const int face = (int)(rem / per_face), side = (int)((rem % per_face) / (uint32_t)p), k = (int)(rem % (uint32_t)p) - 1;
+    const int i = side == 0 ? -1 : (side == 1 ? res : k), j = side == 2 ? -1 : (side == 3 ? res : k);
+    int f2, i2, j2;
+    cube_fold(face, i, j, res, f2, i2, j2);
+    float* base = maps + (size_t)cube * 6u * (size_t)(p * p);
+    base[((size_t)face * p + (j + 1)) * p + (i + 1)] = base[((size_t)f2 * p + (j2 + 1)) * p + (i2 + 1)];
+}
+
+// fills n floats with v
+__global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ dst, float v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
 }  // namespace
 
 void launch_equirect_to_cube(hipStream_t s, const void* pano_rgba32f, int w, int h, uint32_t* dst, int res) {
@@ -253,6 +288,17 @@ void launch_brdf_lut(hipStream_t s, uint32_t* dst, int size, int samples, const 
 }
 void launch_env_pack(hipStream_t s, const void* face_rgba32f, uint32_t* dst, uint32_t n) {
     hipLaunchKernelGGL(k_env_pack, dim3((n + 255) / 256), dim3(256), 0, s, (const float4*)face_rgba32f, dst, n);
+}
+void launch_shadow_cube_border(hipStream_t s, float* maps, int res, uint32_t n_cubes) {
+    const uint32_t n = n_cubes * 6u * 4u * (uint32_t)(res + 2);
+    if (n) hipLaunchKernelGGL(k_shadow_cube_border, dim3((n + 255) / 256), dim3(256), 0, s, maps, res, n_cubes);
+}
+void launch_fill_f32(hipStream_t s, float* dst, float v, size_t n) {
+    if (n) hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, v, n);
+}
+void launch_cube_border(hipStream_t s, const uint32_t* src, uint32_t* dst, int res) {
+    const uint32_t n = 6u * (uint32_t)(res + 2) * (uint32_t)(res + 2);
+    hipLaunchKernelGGL(k_cube_border, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, res);
 }
 void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb) {
     hipLaunchKernelGGL(k_bake_irradiance, dim3((6u * res * res + 255) / 256), dim3(256), 0, s, env, dst, res, tb);

@@ -516,13 +516,13 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
     if (vw.load && !carry && begin >= end) return;  // nothing to add to what the target holds
     const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
     const int tid = (int)threadIdx.x;
-    const size_t plane_px = (size_t)vw.w * vw.h;
+    const size_t plane_px = (size_t)vw.pitch * vw.h;
     if (begin >= end) {                   // nothing drawn here: the tile is just cleared
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int pix = q * T + tid, cx = ox0 + (pix & 15), cy = oy0 + (pix >> 4);
             if (cx < (int)vw.w && cy < (int)vw.h) {
-                const size_t at = (size_t)cy * vw.w + cx;
+                const size_t at = (size_t)cy * vw.pitch + cx;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
                     vw.depth[s * plane_px + at] = carry ? vw.init[s * plane_px + at] : 1.0f;
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
         const bool in_view = px < (int)vw.w && py < (int)vw.h;
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            zi[q][s] = __float_as_uint((vw.load && in_view) ? vw.init[s * plane_px + (size_t)py * vw.w + px] : 1.0f);
+            zi[q][s] = __float_as_uint((vw.load && in_view) ? vw.init[s * plane_px + (size_t)py * vw.pitch + px] : 1.0f);
             lds_key[s * 256 + pix] = (unsigned long long)zi[q][s] << 32;
         }
     }
@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
     for (int q = 0; q < Q; q++) {
         const int pix = q * T + tid, px = ox0 + (pix & 15), py = oy0 + (pix >> 4);
         if (!(px < (int)vw.w && py < (int)vw.h)) continue;
-        const size_t o = (size_t)py * vw.w + px;
+        const size_t o = (size_t)py * vw.pitch + px;
         bool changed = false;
         unsigned long long key[S];
 #pragma unroll

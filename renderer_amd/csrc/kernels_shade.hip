@@ -40,73 +40,95 @@ RDR_DEV F3 fast_normalize(F3 a) { return a * __builtin_amdgcn_rsqf(dot3(a, a)); 
 RDR_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // sampler2DArrayShadow: LINEAR + compare LESS_OR_EQUAL + CLAMP_TO_BORDER(white) (VulkanRendererShadow.cpp:73)
-RDR_DEV float shadow_fetch(const RDR_GLOBAL float* __restrict__ map, int res, int i, int j, float ref) {
-    const float d = (i < 0 || j < 0 || i >= res || j >= res) ? 1.0f : map[(size_t)j * res + i];
-    return ref <= d ? 1.0f : 0.0f;
+typedef float rdr_float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+RDR_DEV void load_pair_f(const RDR_GLOBAL float* p, float& a, float& b) {
+    const rdr_float2_a4 v = *(const RDR_GLOBAL rdr_float2_a4*)p;
+    a = v.x; b = v.y;
 }
+// `map` is the cascade's (res + 4)^2 image with two texels of 1.0 around the interior: a footprint that leaves the
+// map reads the border value there, as CLAMP_TO_BORDER does, without a test.
 RDR_DEV float shadow_pcf(const RDR_GLOBAL float* __restrict__ map, int res, float s, float t, float ref) {
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
-    const int i0 = (int)clampf(fu, -2.0f, (float)res + 1.0f), j0 = (int)clampf(fv, -2.0f, (float)res + 1.0f);
-    const float r00 = shadow_fetch(map, res, i0, j0, ref), r10 = shadow_fetch(map, res, i0 + 1, j0, ref);
-    const float r01 = shadow_fetch(map, res, i0, j0 + 1, ref), r11 = shadow_fetch(map, res, i0 + 1, j0 + 1, ref);
+    const int i0 = (int)clampf(fu, -2.0f, (float)res), j0 = (int)clampf(fv, -2.0f, (float)res);
+    const int pitch = res + 4;
+    const RDR_GLOBAL float* row = map + ((j0 + 2) * pitch + i0 + 2);
+    float d00, d10, d01, d11;
+    load_pair_f(row, d00, d10);
+    load_pair_f(row + pitch, d01, d11);
+    const float r00 = ref <= d00 ? 1.0f : 0.0f, r10 = ref <= d10 ? 1.0f : 0.0f, r01 = ref <= d01 ? 1.0f : 0.0f, r11 = ref <= d11 ? 1.0f : 0.0f;
     const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
     return (1.0f - b) * top + b * bot;
 }
-// samplerCubeArrayShadow
+// samplerCubeArrayShadow. Every face is a (res + 2)^2 image whose border holds the depths across the cube edges
+// (seamless cube filtering), so the footprint is four neighbouring words wherever it lies.
 RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, float rz, float ref) {
-    const int res = (int)fr.point_res;
+    const int res = (int)fr.point_res, pitch = res + 2;
     float s, t;
     const int face = cube_face_fast(rx, ry, rz, s, t);  // the PCF result is continuous in (s,t)
-    const RDR_GLOBAL float* map = as_global(fr.point_shadow) + (size_t)slot * 6 * res * res;  // the six faces of this cube
+    const RDR_GLOBAL float* map = as_global(fr.point_shadow) + (size_t)slot * 6 * pitch * pitch;  // the six faces of this cube
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
     const int i0 = min(max((int)fu, -1), res - 1), j0 = min(max((int)fv, -1), res - 1);
-    uint32_t o[4];
-    cube_footprint(face, i0, j0, res, o);  // texels beyond the face come from its neighbour (seamless cube filtering)
-    const float r00 = ref <= map[o[0]] ? 1.0f : 0.0f, r10 = ref <= map[o[1]] ? 1.0f : 0.0f;
-    const float r01 = ref <= map[o[2]] ? 1.0f : 0.0f, r11 = ref <= map[o[3]] ? 1.0f : 0.0f;
+    const RDR_GLOBAL float* row = map + ((face * pitch + j0 + 1) * pitch + i0 + 1);
+    float d00, d10, d01, d11;
+    load_pair_f(row, d00, d10);
+    load_pair_f(row + pitch, d01, d11);
+    const float r00 = ref <= d00 ? 1.0f : 0.0f, r10 = ref <= d10 ? 1.0f : 0.0f;
+    const float r01 = ref <= d01 ? 1.0f : 0.0f, r11 = ref <= d11 ? 1.0f : 0.0f;
     const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
     return (1.0f - b) * top + b * bot;
 }
 
-RDR_DEV DPointLight load_light(const DPointLight* p) {
-    const RDR_GLOBAL DPointLight* g = as_global(p);
-    // every lane reads the same light: the values are moved to scalar registers, which the 128-register budget of the
-    // shading kernels is not charged for
-    auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
-    DPointLight l;
-    l.px = uni(g->px); l.py = uni(g->py); l.pz = uni(g->pz); l.ix = uni(g->ix); l.iy = uni(g->iy); l.iz = uni(g->iz);
-    l.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)g->flags); l.slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)g->slot);
-    return l;
-}
-
 #define kPI 3.14159274f
 
-// pbr.frag:211-269. Continuous in all arguments: fast math allowed.
-RDR_DEV F3 brdf(F3 radiance, F3 L, F3 N, F3 V, F3 albedo, float roughness, float metallic, F3 F0) {
+// What pbr.frag's BRDF (pbr.frag:211-269) needs of the fragment, worked out once: the terms that do not depend on
+// the light. Continuous in all arguments: fast math allowed.
+struct BrdfFrag {
+    F3 N, V, kdiff, F0, omF0;  // kdiff = (1 - metallic) * albedo / pi, omF0 = 1 - F0
+    float NV, NV1, a2, a2m1, k, omk, gv, c4;
+};
+RDR_DEV BrdfFrag brdf_frag(F3 N, F3 V, F3 albedo, float roughness, float metallic, F3 F0) {
 #pragma clang fp contract(fast)
-    const F3 H = fast_normalize(V + L);
-    const float a = roughness * roughness, a2 = a * a;
-    const float NdotH = clampf(dot3(N, H), 0.0f, 1.0f);
-    float dd = NdotH * NdotH * (a2 - 1.0f) + 1.0f;
+    BrdfFrag f;
+    f.N = N; f.V = V; f.F0 = F0;
+    f.omF0 = f3(1.0f - F0.x, 1.0f - F0.y, 1.0f - F0.z);
+    const float kd = (1.0f - metallic) * (1.0f / kPI);
+    f.kdiff = albedo * kd;
+    f.NV = dot3(N, V);
+    f.NV1 = fmaxf(f.NV, 1e-3f);
+    const float a = roughness * roughness;
+    f.a2 = a * a; f.a2m1 = f.a2 - 1.0f;
+    const float r1 = roughness + 1.0f;
+    f.k = (r1 * r1) * 0.125f; f.omk = 1.0f - f.k;
+    f.gv = f.NV1 * fast_rcp(f.NV1 * f.omk + f.k);  // GeometrySchlickGGX(NdotV)
+    f.c4 = 4.0f * f.NV1;
+    return f;
+}
+// BRDF(1, L, ...) of pbr.frag: the outgoing radiance per unit of light radiance, cosine term included. L need not be
+// normalised (the reference passes the raw light vector for lights without a shadow map, pbr.frag:157-158): LL = L.L,
+// NL = N.L, VL = V.L. The half vector never materialises: with |V| = 1, |V + L|^2 = 1 + 2 V.L + L.L,
+// N.H = (N.V + N.L) / |V + L| and H.V = (1 + V.L) / |V + L|.
+RDR_DEV F3 brdf_eval(const BrdfFrag& f, float LL, float NL, float VL) {
+#pragma clang fp contract(fast)
+    const float rs = __builtin_amdgcn_rsqf(2.0f * VL + (1.0f + LL));
+    const float NdotH = clampf((f.NV + NL) * rs, 0.0f, 1.0f);
+    const float HdotV = clampf((1.0f + VL) * rs, 0.0f, 1.0f);
+    float dd = NdotH * NdotH * f.a2m1 + 1.0f;
     dd = kPI * dd * dd;
-    const float NDF = a2 * fast_rcp(dd);
-    const float r1 = roughness + 1.0f, k = (r1 * r1) * 0.125f;
-    const float NdotV1 = fmaxf(dot3(N, V), 0.001f), NdotL1 = fmaxf(dot3(N, L), 0.001f);
-    const float G = (NdotL1 * fast_rcp(NdotL1 * (1.0f - k) + k)) * (NdotV1 * fast_rcp(NdotV1 * (1.0f - k) + k));
-    const float x = 1.0f - clampf(fmaxf(dot3(H, V), 0.0f), 0.0f, 1.0f);
+    const float NL1 = fmaxf(NL, 1e-3f);
+    const float G = NL1 * fast_rcp(NL1 * f.omk + f.k) * f.gv;
+    const float spec = f.a2 * fast_rcp(dd) * G * fast_rcp(fmaxf(f.c4 * NL1, 1e-5f));
+    const float x = 1.0f - HdotV;
     const float x2 = x * x, x5 = x2 * x2 * x;
-    const float inv_den = fast_rcp(fmaxf(4.0f * fmaxf(dot3(N, V), 1e-3f) * fmaxf(dot3(N, L), 1e-3f), 1e-5f));
-    const float NdotL = fmaxf(dot3(N, L), 0.0f);
-    const float Fx = F0.x + (1.0f - F0.x) * x5, Fy = F0.y + (1.0f - F0.y) * x5, Fz = F0.z + (1.0f - F0.z) * x5;
-    const float om = 1.0f - metallic, inv_pi = 1.0f / kPI;
+    const float NdotL = fmaxf(NL, 0.0f);
+    const float Fx = f.F0.x + f.omF0.x * x5, Fy = f.F0.y + f.omF0.y * x5, Fz = f.F0.z + f.omF0.z * x5;
     F3 o;
-    o.x = ((1.0f - Fx) * om * albedo.x * inv_pi + NDF * G * Fx * inv_den) * radiance.x * NdotL;
-    o.y = ((1.0f - Fy) * om * albedo.y * inv_pi + NDF * G * Fy * inv_den) * radiance.y * NdotL;
-    o.z = ((1.0f - Fz) * om * albedo.z * inv_pi + NDF * G * Fz * inv_den) * radiance.z * NdotL;
+    o.x = ((f.kdiff.x - Fx * f.kdiff.x) + spec * Fx) * NdotL;
+    o.y = ((f.kdiff.y - Fy * f.kdiff.y) + spec * Fy) * NdotL;
+    o.z = ((f.kdiff.z - Fz * f.kdiff.z) + spec * Fz) * NdotL;
     return o;
 }
 
@@ -186,25 +208,30 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
 // MASKED = false for the opaque list, which holds no alpha-masked primitive: the cut-off test and its early
 // exit disappear and the five texture fetches can be in flight together.
 template <bool MASKED>
-RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri& T, int px, int py, float out[4]) {
-    // ---- perspective-correct barycentrics (double) at (px,py), (px+1,py), (px,py+1)
-    const float x0 = fmaf((float)px + 0.5f, fr.inv2W, -1.0f), x1 = fmaf((float)px + 1.5f, fr.inv2W, -1.0f);
-    const float y0 = fmaf((float)py + 0.5f, fr.inv2H, -1.0f), y1 = fmaf((float)py + 1.5f, fr.inv2H, -1.0f);
+RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ lights, const float* srgb, const DShadeTri& T, int px, int py,
+                            float out[4]) {
+    // ---- perspective-correct barycentrics at (px,py) in double (the world position they give feeds shadow compares);
+    // at (px+1,py) and (px,py+1) in single precision from the same planes: those two only give the texture-coordinate
+    // differences the level of detail is chosen from, and filtering is continuous in it
+    const float x0 = fmaf((float)px + 0.5f, fr.inv2W, -1.0f), y0 = fmaf((float)py + 0.5f, fr.inv2H, -1.0f);
     float lam[3][3];
     {
-        double A[3], B[3], C[3];
+        double l[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { A[k] = T.A[k]; B[k] = T.B[k]; C[k] = T.C[k]; }
+        for (int k = 0; k < 3; k++) l[k] = fma(T.A[k], (double)x0, fma(T.B[k], (double)y0, T.C[k]));
+        const double inv = 1.0 / ((l[0] + l[1]) + l[2]);
 #pragma unroll
-        for (int e = 0; e < 3; e++) {
-            const double xn = e == 1 ? x1 : x0, yn = e == 2 ? y1 : y0;
-            double l[3];
+        for (int k = 0; k < 3; k++) lam[0][k] = (float)(l[k] * inv);
+        float lx[3], ly[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) l[k] = fma(A[k], xn, fma(B[k], yn, C[k]));
-            const double inv = 1.0 / ((l[0] + l[1]) + l[2]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) lam[e][k] = (float)(l[k] * inv);
+        for (int k = 0; k < 3; k++) {
+            const float lf = (float)l[k];
+            lx[k] = fmaf((float)T.A[k], fr.inv2W, lf);
+            ly[k] = fmaf((float)T.B[k], fr.inv2H, lf);
         }
+        const float ix = fast_rcp((lx[0] + lx[1]) + lx[2]), iy = fast_rcp((ly[0] + ly[1]) + ly[2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lam[1][k] = lx[k] * ix; lam[2][k] = ly[k] * iy; }
     }
     const F3 P = f3(interp3(lam[0], T.wp[0], T.wp[1], T.wp[2]), interp3(lam[0], T.wp[3], T.wp[4], T.wp[5]), interp3(lam[0], T.wp[6], T.wp[7], T.wp[8]));
     const F3 Nv = f3(interp3(lam[0], T.nrm[0], T.nrm[1], T.nrm[2]), interp3(lam[0], T.nrm[3], T.nrm[4], T.nrm[5]), interp3(lam[0], T.nrm[6], T.nrm[7], T.nrm[8]));
@@ -220,35 +247,72 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
 #endif
     if (RDR_DIAG & 8) { out[0] = P.x + Nv.x + Tv.y + Bv.z; out[1] = u0 + dudx; out[2] = v0 + dvdy + dudy + dvdx; out[3] = 1.0f; return; }
     // ---- pbr.frag main()
-    // the five material textures: filter taps from the albedo texture's geometry, recomputed only for a texture
-    // of another size / wrap mode (decided per wave)
+    // The five material textures. Their filter taps come from the albedo texture's geometry. In the common case,
+    // decided per wave, all five have that geometry and no footprint wraps around an image edge: the texels of all
+    // of them are then loaded in one go (one memory round trip instead of one per texture) and filtered afterwards.
+    // Otherwise a texture of another size or wrap mode gets its own taps and the textures are fetched one by one.
     float t[4] = {0.5f, 0.5f, 0.5f, 1.0f};
-    TexTaps taps0, taps;
-    if (!(RDR_DIAG & 1)) {
-        tex_taps(T.tex[0], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps0);
-        tex_fetch<15>(srgb, T.tex[0], taps0, t);
-    }
-    const float albedo[4] = {t[0] * mt.base_color[0], t[1] * mt.base_color[1], t[2] * mt.base_color[2], t[3] * mt.base_color[3]};
-    if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
-#define RDR_SAMPLE_SLOT(slot, mask)                                                                              \
-    if (!(RDR_DIAG & 1)) {                                                                                       \
-        taps = taps0;                                                                                            \
-        if (!__all(tex_same_geometry(T.tex[slot], T.tex[0]))) tex_taps(T.tex[slot], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps); \
-        tex_fetch<mask>(srgb, T.tex[slot], taps, t);                                                             \
-    }
-    RDR_SAMPLE_SLOT(2, 6)
-    const float metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
-    const float roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
-    RDR_SAMPLE_SLOT(3, 1)
-    const float ao = t[0] * mt.ao;
-    // a zero emissive factor (the glTF default) makes the product zero whatever the texel is: no fetch
+    float albedo[4] = {0.5f * mt.base_color[0], 0.5f * mt.base_color[1], 0.5f * mt.base_color[2], mt.base_color[3]};
+    float metallic = clampf(0.5f * mt.metallic, 0.0f, 1.0f), roughness = clampf(0.5f * mt.roughness, 0.05f, 1.0f), ao = 0.5f * mt.ao;
     float emissive[3] = {0.0f, 0.0f, 0.0f};
-    if (mt.emissive[0] != 0.0f || mt.emissive[1] != 0.0f || mt.emissive[2] != 0.0f) {
-        RDR_SAMPLE_SLOT(4, 7)
-        emissive[0] = t[0] * mt.emissive[0]; emissive[1] = t[1] * mt.emissive[1]; emissive[2] = t[2] * mt.emissive[2];
-    }
-    RDR_SAMPLE_SLOT(1, 7)
+    // a zero emissive factor (the glTF default) makes the product zero whatever the texel is: no fetch
+    const bool has_emissive = mt.emissive[0] != 0.0f || mt.emissive[1] != 0.0f || mt.emissive[2] != 0.0f;
+    if (!(RDR_DIAG & 1)) {
+        // all five descriptors in one burst of loads, before anything branches on them (the geometry test below uses
+        // every one of them, without short-circuit evaluation): one memory round trip instead of one per texture
+        DTexDesc td[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) td[k] = T.tex[k];
+        TexTaps taps0;
+        tex_taps(td[0], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps0);
+        const bool uniform_taps = (int)tex_pairs_adjacent(taps0) & (int)tex_same_geometry(td[1], td[0]) & (int)tex_same_geometry(td[2], td[0]) &
+                                  (int)tex_same_geometry(td[3], td[0]) & (int)tex_same_geometry(td[4], td[0]);
+        if (__all(uniform_taps)) {
+            TexRaw r0, r1, r2, r3, r4;
+            const bool any_emissive = __any(has_emissive) != 0;
+            tex_issue(td[0], taps0, r0);
+            tex_issue(td[2], taps0, r2);
+            tex_issue(td[3], taps0, r3);
+            tex_issue(td[1], taps0, r1);
+            if (any_emissive) tex_issue(td[4], taps0, r4);
+            tex_resolve<15>(srgb, td[0], taps0, r0, t);
+#pragma unroll
+            for (int k = 0; k < 4; k++) albedo[k] = t[k] * mt.base_color[k];
+            if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+            tex_resolve<6>(srgb, td[2], taps0, r2, t);
+            metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
+            roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
+            tex_resolve<1>(srgb, td[3], taps0, r3, t);
+            ao = t[0] * mt.ao;
+            if (any_emissive) {
+                tex_resolve<7>(srgb, td[4], taps0, r4, t);
+                emissive[0] = t[0] * mt.emissive[0]; emissive[1] = t[1] * mt.emissive[1]; emissive[2] = t[2] * mt.emissive[2];
+            }
+            tex_resolve<7>(srgb, td[1], taps0, r1, t);
+        } else {
+            TexTaps taps;
+            tex_fetch<15>(srgb, td[0], taps0, t);
+#pragma unroll
+            for (int k = 0; k < 4; k++) albedo[k] = t[k] * mt.base_color[k];
+            if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+#define RDR_SAMPLE_SLOT(slot, mask)                                                                              \
+            taps = taps0;                                                                                        \
+            if (!__all(tex_same_geometry(td[slot], td[0]))) tex_taps(td[slot], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps); \
+            tex_fetch<mask>(srgb, td[slot], taps, t);
+            RDR_SAMPLE_SLOT(2, 6)
+            metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
+            roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
+            RDR_SAMPLE_SLOT(3, 1)
+            ao = t[0] * mt.ao;
+            if (has_emissive) {
+                RDR_SAMPLE_SLOT(4, 7)
+                emissive[0] = t[0] * mt.emissive[0]; emissive[1] = t[1] * mt.emissive[1]; emissive[2] = t[2] * mt.emissive[2];
+            }
+            RDR_SAMPLE_SLOT(1, 7)
 #undef RDR_SAMPLE_SLOT
+        }
+    } else if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    if (RDR_DIAG & 1) { t[0] = 0.5f; t[1] = 0.5f; t[2] = 1.0f; }
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
     const float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f, nz = t[2] * 2.0f - 1.0f;
     const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
@@ -261,50 +325,63 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
     const F3 F0 = f3(0.04f * om + alb.x * metallic, 0.04f * om + alb.y * metallic, 0.04f * om + alb.z * metallic);
     F3 Lo = f3(0.0f, 0.0f, 0.0f);
 
+    const BrdfFrag bf = brdf_frag(N, V, alb, roughness, metallic, F0);
+
     // ---- point lights (pbr.frag:123-160)
     // depth of the cube-face projection (near .1, far 100): (far - far*near/d) / (far - near) = c0 - c1 / d
     const float c0 = 100.0f / (100.0f - 0.1f), c1 = (100.0f * 0.1f) / (100.0f - 0.1f);
     // Four lights at a time, in two phases: first the light vectors and the shadow-map lookups of all four (their
-    // loads overlap), then the BRDFs. Whether a light casts shadows is uniform, so that branch costs nothing.
-    for (uint32_t base = 0; base < ((RDR_DIAG & 16) ? 0u : fr.n_lights); base += 4u) {
-        F3 Lv[4];
-        float d2[4], sh[4];
+    // loads overlap), then the BRDFs. The light records are read through a kernel argument with a uniform index:
+    // scalar loads into scalar registers. Whether a light casts shadows is uniform, so that branch costs nothing.
+#ifndef RDR_LIGHT_GROUP
+#define RDR_LIGHT_GROUP 4
+#endif
+    const uint32_t n_lights = (RDR_DIAG & 16) ? 0u : fr.n_lights;
+    for (uint32_t base = 0; base < n_lights; base += RDR_LIGHT_GROUP) {
+        float d2[RDR_LIGHT_GROUP], sh[RDR_LIGHT_GROUP], nl[RDR_LIGHT_GROUP], vl[RDR_LIGHT_GROUP];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            sh[j] = 0.0f; d2[j] = 1.0f; Lv[j] = f3(0.0f, 0.0f, 0.0f);
-            if (base + j >= fr.n_lights) continue;
-            const DPointLight pl = load_light(fr.lights + (base + j));
-            Lv[j] = f3(pl.px, pl.py, pl.pz) - P;
-            d2[j] = dot3(Lv[j], Lv[j]);  // distance^2
-            sh[j] = 1.0f;
-            // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says:
-            // neither the shadow map nor the BRDF is evaluated for it.
-            if (!(dot3(N, Lv[j]) > 0.0f)) { sh[j] = 0.0f; continue; }
-            if ((pl.flags & 1u) && (pl.flags & 2u) && !(RDR_DIAG & 32)) {
-                const float lightDepth = fmaxf(fabsf(Lv[j].x), fmaxf(fabsf(Lv[j].y), fabsf(Lv[j].z))) - 0.05f;
+        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
+            sh[j] = 0.0f; d2[j] = 1.0f; nl[j] = 0.0f; vl[j] = 0.0f;
+            if (base + j >= n_lights) continue;  // uniform
+            const DPointLight pl = lights[base + j];
+            const F3 Lv = f3(pl.px, pl.py, pl.pz) - P;
+            d2[j] = dot3(Lv, Lv);  // distance^2
+            nl[j] = dot3(N, Lv);
+            vl[j] = dot3(V, Lv);
+            // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says.
+            // No per-lane branch here: the look-ups of the group's lights then sit in one block of code and their loads
+            // are in flight together; a lane that does not need the result computes it on a valid address and drops it.
+            const bool lit = nl[j] > 0.0f;
+            float shadowTest = 1.0f;
+            if ((pl.flags & 1u) && (pl.flags & 2u) && !(RDR_DIAG & 32)) {  // uniform
+                const float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
                 const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
-                const float shadowTest = shadow_cube(fr, pl.slot, -Lv[j].x, -Lv[j].y, -Lv[j].z, ref);
-                sh[j] = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
+                shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, ref);
+                shadowTest = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
             }
+            sh[j] = lit ? shadowTest : 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (base + j >= fr.n_lights) continue;
-            const DPointLight pl = load_light(fr.lights + (base + j));
+        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
+            if (base + j >= n_lights) continue;
+            const DPointLight pl = lights[base + j];
             // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
-            if (fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2[j] || sh[j] == 0.0f) continue;
-            const float attenuation = fast_rcp(d2[j]);
-            const F3 radiance = f3(pl.ix * attenuation, pl.iy * attenuation, pl.iz * attenuation);
+            const bool on = !(fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2[j]) && sh[j] != 0.0f;
+            if (!__any(on)) continue;  // uniform
             // a light with a shadow map uses the normalised direction, one without does not (pbr.frag:154-158)
-            const float ls = ((pl.flags & 1u) && (pl.flags & 2u)) ? __builtin_amdgcn_rsqf(d2[j]) : 1.0f;
-            const F3 r = brdf(radiance, Lv[j] * ls, N, V, alb, roughness, metallic, F0);
-            Lo = Lo + r * sh[j];
+            const bool unit = (pl.flags & 1u) && (pl.flags & 2u);
+            const float ls = unit ? __builtin_amdgcn_rsqf(d2[j]) : 1.0f;
+            const F3 r = brdf_eval(bf, unit ? 1.0f : d2[j], nl[j] * ls, vl[j] * ls);
+            const float w = on ? fast_rcp(d2[j]) * sh[j] : 0.0f;  // attenuation x shadow
+            Lo = Lo + f3(r.x * (pl.ix * w), r.y * (pl.iy * w), r.z * (pl.iz * w));
         }
     }
 
     // ---- directional light with cascaded shadow maps (pbr.frag:163-183, basic.vert:45-48)
     // (a surface facing away from the light gets max(N.L, 0) = 0 from it: no cascade look-up, no BRDF)
-    if (fr.lights_set && !(RDR_DIAG & 2) && dot3(N, f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2])) > 0.0f) {
+    const F3 dirL = f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2]);
+    const float dir_nl = dot3(N, dirL);
+    if (fr.lights_set && !(RDR_DIAG & 2) && dir_nl > 0.0f) {
         const int ncasc = (int)fr.n_cascades, res = (int)fr.dir_res;
         int split = 0;
         float ls0 = 0.0f, ls1 = 0.0f, ls2 = 0.0f;
@@ -315,16 +392,16 @@ RDR_DEV void shade_fragment(const DFrame& fr, const float* srgb, const DShadeTri
             if (fminf(ls0, ls1) > 1e-2f && fmaxf(ls0, ls1) < 1.0f - 1e-2f) break;
         }
         const int layer = min(split, ncasc - 1);
-        const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * res * res, res, ls0, ls1, ls2);
+        const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * (res + 4) * (res + 4), res, ls0, ls1, ls2);
         if (shadowTest > 1e-3f) {
-            const F3 r = brdf(f3(fr.dir_I[0], fr.dir_I[1], fr.dir_I[2]), f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2]), N, V, alb, roughness, metallic, F0);
-            Lo = Lo + r * shadowTest;
+            const F3 r = brdf_eval(bf, 1.0f, dir_nl, dot3(V, dirL));
+            Lo = Lo + f3(r.x * (fr.dir_I[0] * shadowTest), r.y * (fr.dir_I[1] * shadowTest), r.z * (fr.dir_I[2] * shadowTest));
         }
     }
 
     // ---- image-based lighting (pbr.frag:186-200)
     if (fr.prefiltered.res && fr.irradiance.res && fr.lut_w && !(RDR_DIAG & 4)) {
-        const float NdotV = fmaxf(dot3(N, V), 1e-3f);
+        const float NdotV = bf.NV1;
         const float lod = fminf(roughness * (float)fr.prefiltered.levels, (float)(fr.prefiltered.levels - 1u));
         const float fl = floorf(lod), ff = lod - fl;
         const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, fr.prefiltered.levels - 1u);
@@ -409,7 +486,8 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 #define RDR_SHADE_WAVES 4  // waves per SIMD the register allocation is held to (128 VGPRs)
 #endif
 template <int S>
-__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
+__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
+                                                      const DShadeTri* __restrict__ tris,
                                                       const float* __restrict__ depth, const uint32_t* __restrict__ vis,
                                                       uint2* __restrict__ hdr, uint2* __restrict__ samples_out,
                                                       const uint32_t* __restrict__ blend_start, const uint32_t* __restrict__ blend_end,
@@ -478,7 +556,7 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
         const int fw = (int)(t >> 6), fl = (int)(t & 63u);
         const int fx = tx * RDR_TILE + (fw & 1) * 8 + (fl & 7), fy = ty * RDR_TILE + (fw >> 1) * 8 + (fl >> 3);
         float c[4];
-        shade_fragment<false>(fr, lds_srgb, tris[id], fx, fy, c);
+        shade_fragment<false>(fr, lights, lds_srgb, tris[id], fx, fy, c);
         lds_frag_col[f] = pack_half4(c[0], c[1], c[2], c[3]);
     }
     __syncthreads();
@@ -662,7 +740,8 @@ __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__
 }
 
 // One lane per fragment slot; the grid is fixed and strides over the slots in use.
-__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_blend_shade(const DFrame* __restrict__ frp, const DShadeTri* __restrict__ tris,
+__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_blend_shade(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
+                                                                      const DShadeTri* __restrict__ tris,
                                                                       const uint4* __restrict__ frags, float4* __restrict__ frag_col,
                                                                       const uint32_t* __restrict__ frag_used, uint32_t capacity) {
     __shared__ float lds_srgb[256];
@@ -674,7 +753,7 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_blend_shade(const DFra
         const uint4 m = frags[f];
         if (m.x == BLEND_NONE) continue;
         float c[4];
-        shade_fragment<true>(fr, lds_srgb, tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c);
+        shade_fragment<true>(fr, lights, lds_srgb, tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c);
         frag_col[f] = make_float4(c[0], c[1], c[2], c[3]);
     }
 }
@@ -727,17 +806,17 @@ void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, con
     hipLaunchKernelGGL(k_shade_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, fr, draws, first_tri, n_draws, n_tris, pair_offset, n_after,
                        pair_total, out);
 }
-void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DShadeTri* tris, const float* depth, const uint32_t* vis,
+void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const float* depth, const uint32_t* vis,
                          void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H) {
     const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
     const uint32_t side = 1u << RDR_SHADE_SQ_LOG2;
     const uint32_t grid = ((((W + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) * (((H + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) + 7u) / 8u * 8u * side * side;
     if (samples == 1)
-        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(grid), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
+        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(grid), dim3(256), 0, s, fr, lights, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
     else
-        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(grid), dim3(256), 0, s, fr, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
+        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(grid), dim3(256), 0, s, fr, lights, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
 }
-void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DView* view, const DShadeTri* tris, const DTriRec* recs,
+void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
                          void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity) {
     if (!n_tiles) return;
@@ -747,7 +826,7 @@ void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DVi
     else
         hipLaunchKernelGGL(k_blend_collect<4>, dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
                            frag_used, capacity);
-    hipLaunchKernelGGL(k_blend_shade, dim3(RDR_BLEND_SHADE_BLOCKS), dim3(256), 0, s, fr, tris, (const uint4*)frags, (float4*)frag_col, frag_used, capacity);
+    hipLaunchKernelGGL(k_blend_shade, dim3(RDR_BLEND_SHADE_BLOCKS), dim3(256), 0, s, fr, lights, tris, (const uint4*)frags, (float4*)frag_col, frag_used, capacity);
     if (samples == 1)
         hipLaunchKernelGGL(k_blend_resolve<1>, dim3(n_tiles), dim3(256), 0, s, view, tile_start, tile_end, (const uint4*)frags, (const float4*)frag_col,
                            frag_head, (const uint2*)color, (uint2*)hdr);

@@ -155,6 +155,9 @@ struct rdr_ctx {
     PinBuf h_palette;
     DevBuf d_env, d_irradiance, d_prefiltered, d_lut;
     DCube env{}, irradiance{}, prefiltered{};
+    // the three cubes again with a one-texel border per face (k_cube_border): what the shading kernels filter from
+    DevBuf d_env_b, d_irradiance_b, d_prefiltered_b;
+    DCube env_b{}, irradiance_b{}, prefiltered_b{};
     uint32_t lut_w = 0, lut_h = 0;
 
     // frame targets
@@ -180,6 +183,8 @@ struct rdr_ctx {
     uint64_t blend_pairs = 0, blend_box_pixels = 0;  // of the last batch: (triangle, tile) pairs / box pixels of blended-view triangles
     DevBuf d_frags, d_frag_col, d_frag_head;  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
 
+    bool point_borders_stale = false;   // a face of a point-light cube was (or is about to be) re-rendered: the borders follow
+    uint32_t point_cubes_in_use = 0;
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     // Two frames can be in flight: a frame rendered into a device destination is only enqueued, and the next call builds
     // and enqueues its first half while the GPU still works on this one. Each keeps its own events and its own block
@@ -625,17 +630,33 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
         if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[c->slot ^ 1], 0));
         launch(c->stream, rr[1], none);
     }
+    if (c->point_borders_stale && c->point_cubes_in_use) {
+        // behind every rasteriser launch of this stream that writes point-light faces (static maps were copied in before)
+        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[c->slot ^ 1], 0));
+        launch_shadow_cube_border(c->stream, c->d_point_shadow.as<float>(), (int)c->settings.point_shadow_map_resolution, c->point_cubes_in_use);
+        c->point_borders_stale = false;
+    }
     if (side) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     HIP_TRY(hipGetLastError());
     return RDR_OK;
 }
 
-DView make_view(float* depth, uint32_t* vis, uint32_t w, uint32_t h, uint32_t samples, uint32_t cull, uint32_t load, const float* init = nullptr) {
+DView make_view(float* depth, uint32_t* vis, uint32_t w, uint32_t h, uint32_t samples, uint32_t cull, uint32_t load, const float* init = nullptr,
+                uint32_t pitch = 0) {
     DView v;
     memset(&v, 0, sizeof v);
     v.depth = depth; v.init = init ? init : depth; v.vis = vis; v.w = w; v.h = h; v.samples = samples; v.cull = cull; v.load = load;
+    v.pitch = pitch ? pitch : w;
     return v;
 }
+
+// Shadow targets carry a border the shading kernels filter across without edge cases. A point-light cube face is
+// (res + 2)^2 with one texel of border (the depths across the cube edges, k_shadow_cube_border); a cascade is
+// (res + 4)^2 with two texels of 1.0 (the sampler's opaque-white border, VulkanRendererShadow.cpp:73).
+size_t point_face_texels(const rdr_ctx* c) { const size_t p = (size_t)c->settings.point_shadow_map_resolution + 2; return p * p; }
+size_t point_face_origin(const rdr_ctx* c) { return (size_t)c->settings.point_shadow_map_resolution + 2 + 1; }
+size_t cascade_texels(const rdr_ctx* c) { const size_t p = (size_t)c->settings.directional_shadow_map_resolution + 4; return p * p; }
+size_t cascade_origin(const rdr_ctx* c) { return 2 * ((size_t)c->settings.directional_shadow_map_resolution + 4) + 2; }
 
 // recordPointShadowMapsCommands (VulkanRendererShadow.cpp:255-389)
 int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
@@ -644,11 +665,13 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
     for (uint32_t i = 0; i < c->lights.size(); i++)
         if (c->lights[i].flags & RDR_POINT_LIGHT_CAST_SHADOWS) casters.push_back(i);
     if (casters.empty() || count == 0) return RDR_OK;
-    const uint32_t res = c->settings.point_shadow_map_resolution;
-    const size_t face_px = (size_t)res * res, total_bytes = face_px * 6 * count * 4;
+    const uint32_t res = c->settings.point_shadow_map_resolution, pitch = res + 2;
+    const size_t face_px = point_face_texels(c), origin = point_face_origin(c), total_bytes = face_px * 6 * count * 4;
     if (c->d_point_shadow.cap < total_bytes) {
         HIP_TRY(c->d_point_shadow.ensure(total_bytes));
         HIP_TRY(c->d_point_static.ensure(total_bytes));
+        launch_fill_f32(c->stream, c->d_point_shadow.as<float>(), 1.0f, face_px * 6 * count);
+        launch_fill_f32(c->stream, c->d_point_static.as<float>(), 1.0f, face_px * 6 * count);
     }
     static const vec3 dirs[6] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
     static const vec3 ups[6] = {{0, 1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};
@@ -690,8 +713,8 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
         for (int j = 0; j < 6; j++) {
             face[j].position = l.point;
             const mat4 vp = face[j].view_proj();
-            float* dst = c->d_point_static.as<float>() + ((size_t)l.slot * 6 + j) * face_px;
-            sb.views.push_back(make_view(dst, nullptr, res, res, 1, 1, 0));
+            float* dst = c->d_point_static.as<float>() + ((size_t)l.slot * 6 + j) * face_px + origin;
+            sb.views.push_back(make_view(dst, nullptr, res, res, 1, 1, 0, nullptr, pitch));
             append_draws(c, static_prims, vp, l.point, SORT_FRONT_TO_BACK, (uint32_t)sb.views.size() - 1, sb.draws);
         }
         l.flags |= RDR_POINT_LIGHT_STATIC_SHADOW_MAP_RENDERED;
@@ -705,7 +728,9 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
             HIP_TRY(hipMemcpyAsync(c->d_point_shadow.as<float>() + off, c->d_point_static.as<float>() + off, 6 * face_px * 4,
                                    hipMemcpyDeviceToDevice, c->stream));
         }
+        c->point_borders_stale = true;
     }
+    c->point_cubes_in_use = (uint32_t)slotted.size();
     // dynamic meshes on top of the static face: the rasteriser starts every tile of such a face from the cached static
     // map (DView::init) and writes the result to the map the shaders read, so the static map is never copied
     for (uint32_t i : slotted) {
@@ -716,9 +741,10 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
             const size_t n_before = dynamic_batch.draws.size();
             append_draws(c, dynamic_prims, vp, l.point, SORT_FRONT_TO_BACK, (uint32_t)dynamic_batch.views.size(), dynamic_batch.draws);
             if (c->settings.dynamic_shadows_enabled && dynamic_batch.draws.size() > n_before) {
-                const size_t off = ((size_t)l.slot * 6 + j) * face_px;
+                const size_t off = ((size_t)l.slot * 6 + j) * face_px + origin;
                 dynamic_batch.views.push_back(make_view(c->d_point_shadow.as<float>() + off, nullptr, res, res, 1, 1, 1,
-                                                        c->d_point_static.as<float>() + off));
+                                                        c->d_point_static.as<float>() + off, pitch));
+                c->point_borders_stale = true;
             } else {
                 dynamic_batch.draws.resize(n_before);
             }
@@ -730,8 +756,11 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
 // recordDirectionalShadowMapsCommands (VulkanRendererShadow.cpp:391-456)
 int cascade_views(rdr_ctx* c, Batch& b) {
     const uint32_t levels = c->settings.directional_shadow_cascade_levels, res = c->settings.directional_shadow_map_resolution;
-    const size_t px = (size_t)res * res;
-    HIP_TRY(c->d_dir_shadow.ensure(px * levels * 4));
+    const size_t px = cascade_texels(c);
+    if (c->d_dir_shadow.cap < px * levels * 4) {
+        HIP_TRY(c->d_dir_shadow.ensure(px * levels * 4));
+        launch_fill_f32(c->stream, c->d_dir_shadow.as<float>(), 1.0f, px * levels);  // the border keeps this value; the rasteriser writes the interior
+    }
     Camera light;  // DirectionalLight::lightViewCamera (DirectionalLight.cpp:3-5)
     light.type = 1;
     light.position = make3(c->dir_light.position[0], c->dir_light.position[1], c->dir_light.position[2]);
@@ -763,7 +792,7 @@ int cascade_views(rdr_ctx* c, Batch& b) {
         split_pov.crop = mat_mul(mat_scale(make3(1.0f / largest, 1.0f / largest, 1.0f)), mat_translate(offset));
         const mat4 vp = split_pov.view_proj();
         c->csm_viewproj[i] = vp;
-        b.views.push_back(make_view(c->d_dir_shadow.as<float>() + (size_t)i * px, nullptr, res, res, 1, 1, 0));
+        b.views.push_back(make_view(c->d_dir_shadow.as<float>() + (size_t)i * px + cascade_origin(c), nullptr, res, res, 1, 1, 0, nullptr, res + 4));
         append_draws(c, all, vp, split_pov.position, SORT_FRONT_TO_BACK, (uint32_t)b.views.size() - 1, b.draws);
     }
     return RDR_OK;
@@ -897,7 +926,7 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     if (c->stream4) (void)hipStreamSynchronize(c->stream4);
     DevBuf* bufs[] = {&c->d_pos, &c->d_attr, &c->d_idx, &c->d_prims, &c->d_textures, &c->d_tables, &c->d_trig, &c->d_env,
-                      &c->d_irradiance, &c->d_prefiltered, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
+                      &c->d_irradiance, &c->d_prefiltered, &c->d_env_b, &c->d_irradiance_b, &c->d_prefiltered_b, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
                       &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
                       &c->d_counters, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
@@ -1230,6 +1259,24 @@ static int bake_environment(rdr_ctx* c, uint32_t w) {
                                   c->d_trig.as<float>());
         c->prefiltered.texels = c->d_prefiltered.as<uint32_t>(); c->prefiltered.res = base; c->prefiltered.levels = levels;
     }
+    // bordered copies for the shading kernels
+    auto add_border = [&](const DCube& src, DevBuf& buf, DCube& dst) -> int {
+        dst = src;
+        size_t off = 0;
+        for (uint32_t l = 0; l < src.levels; l++) {
+            const size_t r = std::max(1u, src.res >> l);
+            dst.level_offset[l] = (uint32_t)off;
+            off += 6 * (r + 2) * (r + 2);
+        }
+        HIP_TRY(buf.ensure(off * 4 + 16));  // the shading kernels read texel pairs: one texel of slack
+        for (uint32_t l = 0; l < src.levels; l++)
+            launch_cube_border(c->stream, src.texels + src.level_offset[l], buf.as<uint32_t>() + dst.level_offset[l], (int)std::max(1u, src.res >> l));
+        dst.texels = buf.as<uint32_t>();
+        return RDR_OK;
+    };
+    RDR_TRY(add_border(c->env, c->d_env_b, c->env_b));
+    RDR_TRY(add_border(c->irradiance, c->d_irradiance_b, c->irradiance_b));
+    RDR_TRY(add_border(c->prefiltered, c->d_prefiltered_b, c->prefiltered_b));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     return RDR_OK;
@@ -1424,7 +1471,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         HIP_TRY(c->d_frame.ensure(off_l + sz_l));
         c->d_lights.p = c->d_frame.as<uint8_t>() + off_l;
         fr.lights = c->d_lights.as<DPointLight>();
-        fr.env = c->env; fr.irradiance = c->irradiance; fr.prefiltered = c->prefiltered;
+        fr.env = c->env_b; fr.irradiance = c->irradiance_b; fr.prefiltered = c->prefiltered_b;  // bordered copies
         fr.lut = c->d_lut.as<uint8_t>(); fr.lut_w = c->lut_w; fr.lut_h = c->lut_h;
         fr.textures = c->d_textures.as<DTexture>(); fr.prims = c->d_prims.as<DPrim>();
         fr.pos = c->d_pos.as<float4>(); fr.attr = c->d_attr.as<DVertexAttr>(); fr.idx = c->d_idx.as<uint32_t>();
@@ -1465,7 +1512,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     // behind the previous frame's shading and tail
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev[1], 0));
     HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
-    launch_shade_opaque(c->stream2, (int)S, c->d_frame.as<DFrame>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
+    launch_shade_opaque(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
                         (S == 4 && have_blend) ? c->d_samples.p : nullptr, c->d_tile_start.as<uint32_t>() + blend_tile_base,
                         c->d_tile_end.as<uint32_t>() + blend_tile_base, W, H);
     HIP_TRY(hipEventRecord(c->ev[7], c->stream2));
@@ -1483,7 +1530,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         HIP_TRY(c->d_frags.ensure(capacity * 16));
         HIP_TRY(c->d_frag_col.ensure(capacity * 16));
         HIP_TRY(c->d_frag_head.ensure(n * 4));
-        launch_raster_blend(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
+        launch_raster_blend(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
                             c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
                             c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p, c->d_frag_col.p,
                             c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, (uint32_t)capacity);
@@ -1552,6 +1599,17 @@ static int read_back(rdr_ctx* c, void* dst, const void* src, size_t bytes) {
     return RDR_OK;
 }
 
+// rows of `w` floats, `pitch` floats apart on the device, packed on the host
+static int read_back_2d(rdr_ctx* c, float* dst, const float* src, size_t pitch, size_t w, size_t h) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream3));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
+    HIP_TRY(hipStreamSynchronize(c->stream4));
+    HIP_TRY(hipMemcpy2D(dst, w * 4, src, pitch * 4, w * 4, h, hipMemcpyDeviceToHost));
+    return RDR_OK;
+}
+
 int rdr_read_depth(rdr_ctx* c, float* out) {
     if (!c || !out || !c->have_frame) return fail(c, RDR_ERR_INVALID, "read_depth: no frame");
     return read_back(c, out, c->d_depth.p, (size_t)c->W * c->H * c->settings.msaa * 4);
@@ -1562,13 +1620,13 @@ int rdr_read_visibility(rdr_ctx* c, uint32_t* out) {
 }
 int rdr_read_directional_shadow(rdr_ctx* c, uint32_t index, float* out) {
     if (!c || !out || !c->have_frame || !c->lights_set || index >= c->settings.directional_shadow_cascade_levels) return fail(c, RDR_ERR_INVALID, "read_directional_shadow");
-    const size_t px = (size_t)c->settings.directional_shadow_map_resolution * c->settings.directional_shadow_map_resolution;
-    return read_back(c, out, c->d_dir_shadow.as<float>() + index * px, px * 4);
+    const uint32_t res = c->settings.directional_shadow_map_resolution;
+    return read_back_2d(c, out, c->d_dir_shadow.as<float>() + index * cascade_texels(c) + cascade_origin(c), res + 4, res, res);
 }
 int rdr_read_point_shadow(rdr_ctx* c, uint32_t slot, uint32_t face, float* out) {
-    const size_t px = c ? (size_t)c->settings.point_shadow_map_resolution * c->settings.point_shadow_map_resolution : 0;
     if (!c || !out || face >= 6 || slot >= c->settings.point_shadow_map_count || !c->d_point_shadow.p) return fail(c, RDR_ERR_INVALID, "read_point_shadow");
-    return read_back(c, out, c->d_point_shadow.as<float>() + ((size_t)slot * 6 + face) * px, px * 4);
+    const uint32_t res = c->settings.point_shadow_map_resolution;
+    return read_back_2d(c, out, c->d_point_shadow.as<float>() + ((size_t)slot * 6 + face) * point_face_texels(c) + point_face_origin(c), res + 2, res, res);
 }
 int rdr_read_hdr(rdr_ctx* c, float* out) {
     if (!c || !out || !c->have_post) return fail(c, RDR_ERR_INVALID, "read_hdr: nothing rendered");

@@ -61,6 +61,7 @@ struct DView {
     uint32_t tiles_x, tiles_y;
     uint32_t tile_base;  // first global tile id of this view
     uint32_t load;       // 0: start from depth 1.0, 1: start from what `init` holds, 2: binned only (the blended pass rasterises it)
+    uint32_t pitch;      // texels from one row of depth / init / vis to the next (>= w: shadow targets carry a border the shaders filter across)
 };
 
 // One draw = one primitive seen from one view.
@@ -137,8 +138,8 @@ struct DFrame {
     uint32_t n_cascades, dir_res, point_res, lights_set;
     float dir_L[3];          // normalised direction towards... exactly directionalLight.direction normalised
     float dir_I[3];
-    const float* dir_shadow;    // [cascade][res][res]
-    const float* point_shadow;  // [slot*6+face][res][res]
+    const float* dir_shadow;    // [cascade][res + 4][res + 4]: two texels of border holding 1.0 (clamp-to-border, white)
+    const float* point_shadow;  // [slot*6+face][res + 2][res + 2]: one texel of border holding the texels across the cube edges
     const DPointLight* lights;
     DCube env, irradiance, prefiltered;
     const uint8_t* lut;  // RGBA8
