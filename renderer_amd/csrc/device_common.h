@@ -191,6 +191,7 @@ RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, 
 // Variants for shading, where the result is continuous in the direction: the
 // face coordinates use the hardware reciprocal instead of two IEEE divides.
 RDR_DEV int cube_face_fast(float rx, float ry, float rz, float& s, float& t) {
+#pragma clang fp contract(fast)
     const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
     int face; float sc, tc, ma;
     if (az >= ax && az >= ay) { face = rz < 0.0f ? 5 : 4; sc = rz < 0.0f ? -rx : rx; tc = -ry; ma = az; }
@@ -204,6 +205,7 @@ RDR_DEV int cube_face_fast(float rx, float ry, float rz, float& s, float& t) {
 // `cube` is a bordered copy (k_cube_border): the footprint at (i0, j0), i0 and j0 in [-1, r - 1], is two pairs of
 // neighbouring words, no edge handling.
 RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
+#pragma clang fp contract(fast)
     float s, t;
     const int face = cube_face_fast(dx, dy, dz, s, t);
     const uint32_t rr = cube.res >> level;
@@ -262,6 +264,7 @@ RDR_DEV uint32_t tex_level_offset(const DTexDesc& t, const DTexture* __restrict_
 // needs no integer modulo; the weight differs from the unwrapped formula only by rounding, and bilinear filtering
 // is continuous across texel boundaries.
 RDR_DEV void tex_axis(float coord, int n, uint32_t mode, int& i0, int& i1, float& a) {
+#pragma clang fp contract(fast)
     if (mode == 0u) coord -= floorf(coord);
     const float tc = coord * (float)n - 0.5f;
     const float fc = floorf(tc);
@@ -298,6 +301,7 @@ RDR_DEV void tex_level_taps(const DTexDesc& t, const DTexture* __restrict__ tabl
 // texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2)
 RDR_DEV void tex_taps(const DTexDesc& t, const DTexture* __restrict__ table, float u, float v, float dudx, float dvdx, float dudy, float dvdy,
                       TexTaps& o) {
+#pragma clang fp contract(fast)
     const uint32_t levels = t.info & 31u;
     float lambda = 0.0f;
     if (levels > 1u) {

@@ -36,7 +36,9 @@ namespace {
 
 RDR_DEV float interp3(const float lam[3], float a0, float a1, float a2) { return fmaf(lam[2], a2, fmaf(lam[1], a1, lam[0] * a0)); }
 
-RDR_DEV F3 fast_normalize(F3 a) { return a * __builtin_amdgcn_rsqf(dot3(a, a)); }
+// dot product as two fused multiply-adds: for the continuous parts of shading only (the exact paths use dot3)
+RDR_DEV float dot3f(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+RDR_DEV F3 fast_normalize(F3 a) { return a * __builtin_amdgcn_rsqf(dot3f(a, a)); }
 RDR_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // sampler2DArrayShadow: LINEAR + compare LESS_OR_EQUAL + CLAMP_TO_BORDER(white) (VulkanRendererShadow.cpp:73)
@@ -48,6 +50,7 @@ RDR_DEV void load_pair_f(const RDR_GLOBAL float* p, float& a, float& b) {
 // `map` is the cascade's (res + 4)^2 image with two texels of 1.0 around the interior: a footprint that leaves the
 // map reads the border value there, as CLAMP_TO_BORDER does, without a test.
 RDR_DEV float shadow_pcf(const RDR_GLOBAL float* __restrict__ map, int res, float s, float t, float ref) {
+#pragma clang fp contract(fast)
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
@@ -64,6 +67,7 @@ RDR_DEV float shadow_pcf(const RDR_GLOBAL float* __restrict__ map, int res, floa
 // samplerCubeArrayShadow. Every face is a (res + 2)^2 image whose border holds the depths across the cube edges
 // (seamless cube filtering), so the footprint is four neighbouring words wherever it lies.
 RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, float rz, float ref) {
+#pragma clang fp contract(fast)
     const int res = (int)fr.point_res, pitch = res + 2;
     float s, t;
     const int face = cube_face_fast(rx, ry, rz, s, t);  // the PCF result is continuous in (s,t)
@@ -97,7 +101,7 @@ RDR_DEV BrdfFrag brdf_frag(F3 N, F3 V, F3 albedo, float roughness, float metalli
     f.omF0 = f3(1.0f - F0.x, 1.0f - F0.y, 1.0f - F0.z);
     const float kd = (1.0f - metallic) * (1.0f / kPI);
     f.kdiff = albedo * kd;
-    f.NV = dot3(N, V);
+    f.NV = dot3f(N, V);
     f.NV1 = fmaxf(f.NV, 1e-3f);
     const float a = roughness * roughness;
     f.a2 = a * a; f.a2m1 = f.a2 - 1.0f;
@@ -210,6 +214,9 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
 template <bool MASKED>
 RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ lights, const float* srgb, const DShadeTri& T, int px, int py,
                             float out[4]) {
+    // Multiply-add pairs may fuse in this function: what must round as in the CPU checker is written with explicit
+    // fma / fmaf calls or sits in the cascade block below, which switches fusing off again.
+#pragma clang fp contract(fast)
     // ---- perspective-correct barycentrics at (px,py) in double (the world position they give feeds shadow compares);
     // at (px+1,py) and (px,py+1) in single precision from the same planes: those two only give the texture-coordinate
     // differences the level of detail is chosen from, and filtering is continuous in it
@@ -240,6 +247,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
     const float u0 = interp3(lam[0], T.uv[0], T.uv[1], T.uv[2]), v0 = interp3(lam[0], T.uv[3], T.uv[4], T.uv[5]);
     const float dudx = interp3(lam[1], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdx = interp3(lam[1], T.uv[3], T.uv[4], T.uv[5]) - v0;
     const float dudy = interp3(lam[2], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdy = interp3(lam[2], T.uv[3], T.uv[4], T.uv[5]) - v0;
+    __builtin_amdgcn_sched_barrier(0);  // the loads below stay below: the record is consumed in stages, not held whole
     const DShadeTri& mt = T;  // material block and texture descriptors travel with the triangle
 
 #ifndef RDR_DIAG
@@ -254,7 +262,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
     float t[4] = {0.5f, 0.5f, 0.5f, 1.0f};
     float albedo[4] = {0.5f * mt.base_color[0], 0.5f * mt.base_color[1], 0.5f * mt.base_color[2], mt.base_color[3]};
     float metallic = clampf(0.5f * mt.metallic, 0.0f, 1.0f), roughness = clampf(0.5f * mt.roughness, 0.05f, 1.0f), ao = 0.5f * mt.ao;
-    float emissive[3] = {0.0f, 0.0f, 0.0f};
+    float emissive[3] = {0.0f, 0.0f, 0.0f}, nmap[3] = {0.5f, 0.5f, 1.0f};
     // a zero emissive factor (the glTF default) makes the product zero whatever the texel is: no fetch
     const bool has_emissive = mt.emissive[0] != 0.0f || mt.emissive[1] != 0.0f || mt.emissive[2] != 0.0f;
     if (!(RDR_DIAG & 1)) {
@@ -268,27 +276,42 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const bool uniform_taps = (int)tex_pairs_adjacent(taps0) & (int)tex_same_geometry(td[1], td[0]) & (int)tex_same_geometry(td[2], td[0]) &
                                   (int)tex_same_geometry(td[3], td[0]) & (int)tex_same_geometry(td[4], td[0]);
         if (__all(uniform_taps)) {
+            // RDR_TEX_SERIAL: one texture at a time (five memory round trips, few registers: the kernel then fits more
+            // waves per SIMD, which hide the round trips); otherwise all loads in flight together (one round trip, forty
+            // registers of texels). The empty asm statements keep the compiler from moving the loads back together.
+#ifndef RDR_TEX_SERIAL
+#define RDR_TEX_SERIAL 0
+#endif
+#define RDR_TEX_FENCE() do { if (RDR_TEX_SERIAL) asm volatile("" ::: "memory"); } while (0)
             TexRaw r0, r1, r2, r3, r4;
             const bool any_emissive = __any(has_emissive) != 0;
-            tex_issue(td[0], taps0, r0);
-            tex_issue(td[2], taps0, r2);
-            tex_issue(td[3], taps0, r3);
             tex_issue(td[1], taps0, r1);
-            if (any_emissive) tex_issue(td[4], taps0, r4);
+            if (!RDR_TEX_SERIAL) { tex_issue(td[0], taps0, r0); tex_issue(td[2], taps0, r2); }
+            tex_resolve<7>(srgb, td[1], taps0, r1, t);
+            nmap[0] = t[0]; nmap[1] = t[1]; nmap[2] = t[2];
+            RDR_TEX_FENCE();
+            if (RDR_TEX_SERIAL) tex_issue(td[0], taps0, r0);
+            else { tex_issue(td[3], taps0, r3); if (any_emissive) tex_issue(td[4], taps0, r4); }
             tex_resolve<15>(srgb, td[0], taps0, r0, t);
 #pragma unroll
             for (int k = 0; k < 4; k++) albedo[k] = t[k] * mt.base_color[k];
             if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+            RDR_TEX_FENCE();
+            if (RDR_TEX_SERIAL) tex_issue(td[2], taps0, r2);
             tex_resolve<6>(srgb, td[2], taps0, r2, t);
             metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
             roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
+            RDR_TEX_FENCE();
+            if (RDR_TEX_SERIAL) tex_issue(td[3], taps0, r3);
             tex_resolve<1>(srgb, td[3], taps0, r3, t);
             ao = t[0] * mt.ao;
             if (any_emissive) {
+                RDR_TEX_FENCE();
+                if (RDR_TEX_SERIAL) tex_issue(td[4], taps0, r4);
                 tex_resolve<7>(srgb, td[4], taps0, r4, t);
                 emissive[0] = t[0] * mt.emissive[0]; emissive[1] = t[1] * mt.emissive[1]; emissive[2] = t[2] * mt.emissive[2];
             }
-            tex_resolve<7>(srgb, td[1], taps0, r1, t);
+            RDR_TEX_FENCE();
         } else {
             TexTaps taps;
             tex_fetch<15>(srgb, td[0], taps0, t);
@@ -309,97 +332,28 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
                 emissive[0] = t[0] * mt.emissive[0]; emissive[1] = t[1] * mt.emissive[1]; emissive[2] = t[2] * mt.emissive[2];
             }
             RDR_SAMPLE_SLOT(1, 7)
+            nmap[0] = t[0]; nmap[1] = t[1]; nmap[2] = t[2];
 #undef RDR_SAMPLE_SLOT
         }
     } else if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
-    if (RDR_DIAG & 1) { t[0] = 0.5f; t[1] = 0.5f; t[2] = 1.0f; }
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
-    const float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f, nz = t[2] * 2.0f - 1.0f;
+    const float nx = nmap[0] * 2.0f - 1.0f, ny = nmap[1] * 2.0f - 1.0f, nz = nmap[2] * 2.0f - 1.0f;
     const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
     const F3 cam = f3(fr.cam[0], fr.cam[1], fr.cam[2]);
     const F3 V = fast_normalize(cam - P);
     const F3 negV = V * -1.0f;
-    const F3 Rv = negV - N * (2.0f * dot3(N, negV));
+    const F3 Rv = negV - N * (2.0f * dot3f(N, negV));
     const F3 alb = f3(albedo[0], albedo[1], albedo[2]);
     const float om = 1.0f - metallic;
     const F3 F0 = f3(0.04f * om + alb.x * metallic, 0.04f * om + alb.y * metallic, 0.04f * om + alb.z * metallic);
-    F3 Lo = f3(0.0f, 0.0f, 0.0f);
+    // the sum pbr.frag forms as Lo + emissive, in another order: emissive first, then the image-based term (its
+    // inputs - reflection vector, occlusion, table look-up - are then dead before the light loop), then the lights
+    F3 Lo = f3(emissive[0], emissive[1], emissive[2]);
 
     const BrdfFrag bf = brdf_frag(N, V, alb, roughness, metallic, F0);
 
-    // ---- point lights (pbr.frag:123-160)
-    // depth of the cube-face projection (near .1, far 100): (far - far*near/d) / (far - near) = c0 - c1 / d
-    const float c0 = 100.0f / (100.0f - 0.1f), c1 = (100.0f * 0.1f) / (100.0f - 0.1f);
-    // Four lights at a time, in two phases: first the light vectors and the shadow-map lookups of all four (their
-    // loads overlap), then the BRDFs. The light records are read through a kernel argument with a uniform index:
-    // scalar loads into scalar registers. Whether a light casts shadows is uniform, so that branch costs nothing.
-#ifndef RDR_LIGHT_GROUP
-#define RDR_LIGHT_GROUP 4
-#endif
-    const uint32_t n_lights = (RDR_DIAG & 16) ? 0u : fr.n_lights;
-    for (uint32_t base = 0; base < n_lights; base += RDR_LIGHT_GROUP) {
-        float d2[RDR_LIGHT_GROUP], sh[RDR_LIGHT_GROUP], nl[RDR_LIGHT_GROUP], vl[RDR_LIGHT_GROUP];
-#pragma unroll
-        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
-            sh[j] = 0.0f; d2[j] = 1.0f; nl[j] = 0.0f; vl[j] = 0.0f;
-            if (base + j >= n_lights) continue;  // uniform
-            const DPointLight pl = lights[base + j];
-            const F3 Lv = f3(pl.px, pl.py, pl.pz) - P;
-            d2[j] = dot3(Lv, Lv);  // distance^2
-            nl[j] = dot3(N, Lv);
-            vl[j] = dot3(V, Lv);
-            // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says.
-            // No per-lane branch here: the look-ups of the group's lights then sit in one block of code and their loads
-            // are in flight together; a lane that does not need the result computes it on a valid address and drops it.
-            const bool lit = nl[j] > 0.0f;
-            float shadowTest = 1.0f;
-            if ((pl.flags & 1u) && (pl.flags & 2u) && !(RDR_DIAG & 32)) {  // uniform
-                const float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
-                const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
-                shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, ref);
-                shadowTest = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
-            }
-            sh[j] = lit ? shadowTest : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
-            if (base + j >= n_lights) continue;
-            const DPointLight pl = lights[base + j];
-            // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
-            const bool on = !(fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2[j]) && sh[j] != 0.0f;
-            if (!__any(on)) continue;  // uniform
-            // a light with a shadow map uses the normalised direction, one without does not (pbr.frag:154-158)
-            const bool unit = (pl.flags & 1u) && (pl.flags & 2u);
-            const float ls = unit ? __builtin_amdgcn_rsqf(d2[j]) : 1.0f;
-            const F3 r = brdf_eval(bf, unit ? 1.0f : d2[j], nl[j] * ls, vl[j] * ls);
-            const float w = on ? fast_rcp(d2[j]) * sh[j] : 0.0f;  // attenuation x shadow
-            Lo = Lo + f3(r.x * (pl.ix * w), r.y * (pl.iy * w), r.z * (pl.iz * w));
-        }
-    }
-
-    // ---- directional light with cascaded shadow maps (pbr.frag:163-183, basic.vert:45-48)
-    // (a surface facing away from the light gets max(N.L, 0) = 0 from it: no cascade look-up, no BRDF)
-    const F3 dirL = f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2]);
-    const float dir_nl = dot3(N, dirL);
-    if (fr.lights_set && !(RDR_DIAG & 2) && dir_nl > 0.0f) {
-        const int ncasc = (int)fr.n_cascades, res = (int)fr.dir_res;
-        int split = 0;
-        float ls0 = 0.0f, ls1 = 0.0f, ls2 = 0.0f;
-        for (; split < ncasc; split++) {
-            const F4 lsp = xform_point(fr.csm_viewproj[split], P.x, P.y, P.z);
-            ls0 = lsp.x * 0.5f + 0.5f; ls1 = lsp.y * 0.5f + 0.5f; ls2 = lsp.z;
-            if (lsp.w != 1.0f) { ls0 /= lsp.w; ls1 /= lsp.w; ls2 /= lsp.w; }
-            if (fminf(ls0, ls1) > 1e-2f && fmaxf(ls0, ls1) < 1.0f - 1e-2f) break;
-        }
-        const int layer = min(split, ncasc - 1);
-        const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * (res + 4) * (res + 4), res, ls0, ls1, ls2);
-        if (shadowTest > 1e-3f) {
-            const F3 r = brdf_eval(bf, 1.0f, dir_nl, dot3(V, dirL));
-            Lo = Lo + f3(r.x * (fr.dir_I[0] * shadowTest), r.y * (fr.dir_I[1] * shadowTest), r.z * (fr.dir_I[2] * shadowTest));
-        }
-    }
-
     // ---- image-based lighting (pbr.frag:186-200)
+    auto image_based = [&]() {
     if (fr.prefiltered.res && fr.irradiance.res && fr.lut_w && !(RDR_DIAG & 4)) {
         const float NdotV = bf.NV1;
         const float lod = fminf(roughness * (float)fr.prefiltered.levels, (float)(fr.prefiltered.levels - 1u));
@@ -437,9 +391,89 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         }
         Lo = Lo + f3(add[0], add[1], add[2]);
     }
-    out[0] = fminf(Lo.x + emissive[0], 10.0f);
-    out[1] = fminf(Lo.y + emissive[1], 10.0f);
-    out[2] = fminf(Lo.z + emissive[2], 10.0f);
+    };
+#ifndef RDR_IBL_FIRST
+#define RDR_IBL_FIRST 1
+#endif
+    if (RDR_IBL_FIRST) image_based();
+
+    // ---- point lights (pbr.frag:123-160)
+    // depth of the cube-face projection (near .1, far 100): (far - far*near/d) / (far - near) = c0 - c1 / d
+    const float c0 = 100.0f / (100.0f - 0.1f), c1 = (100.0f * 0.1f) / (100.0f - 0.1f);
+    // RDR_LIGHT_GROUP lights at a time, in two phases: first the light vectors and the shadow-map lookups of the group
+    // (their loads overlap), then the BRDFs. The light records are read through a kernel argument with a uniform index:
+    // scalar loads into scalar registers. Whether a light casts shadows is uniform, so that branch costs nothing.
+#ifndef RDR_LIGHT_GROUP
+#define RDR_LIGHT_GROUP 2
+#endif
+    const uint32_t n_lights = (RDR_DIAG & 16) ? 0u : fr.n_lights;
+    for (uint32_t base = 0; base < n_lights; base += RDR_LIGHT_GROUP) {
+        float d2[RDR_LIGHT_GROUP], sh[RDR_LIGHT_GROUP], nl[RDR_LIGHT_GROUP], vl[RDR_LIGHT_GROUP];
+#pragma unroll
+        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
+            sh[j] = 0.0f; d2[j] = 1.0f; nl[j] = 0.0f; vl[j] = 0.0f;
+            if (base + j >= n_lights) continue;  // uniform
+            const DPointLight pl = lights[base + j];
+            const F3 Lv = f3(pl.px, pl.py, pl.pz) - P;
+            d2[j] = dot3f(Lv, Lv);  // distance^2
+            nl[j] = dot3f(N, Lv);
+            vl[j] = dot3f(V, Lv);
+            // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says.
+            // No per-lane branch here: the look-ups of the group's lights then sit in one block of code and their loads
+            // are in flight together; a lane that does not need the result computes it on a valid address and drops it.
+            const bool lit = nl[j] > 0.0f;
+            float shadowTest = 1.0f;
+            if ((pl.flags & 1u) && (pl.flags & 2u) && !(RDR_DIAG & 32)) {  // uniform
+                const float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
+                const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
+                shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, ref);
+                shadowTest = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
+            }
+            sh[j] = lit ? shadowTest : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
+            if (base + j >= n_lights) continue;
+            const DPointLight pl = lights[base + j];
+            // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
+            const bool on = !(fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2[j]) && sh[j] != 0.0f;
+            if (!__any(on)) continue;  // uniform
+            // a light with a shadow map uses the normalised direction, one without does not (pbr.frag:154-158)
+            const bool unit = (pl.flags & 1u) && (pl.flags & 2u);
+            const float ls = unit ? __builtin_amdgcn_rsqf(d2[j]) : 1.0f;
+            const F3 r = brdf_eval(bf, unit ? 1.0f : d2[j], nl[j] * ls, vl[j] * ls);
+            const float w = on ? fast_rcp(d2[j]) * sh[j] : 0.0f;  // attenuation x shadow
+            Lo = Lo + f3(r.x * (pl.ix * w), r.y * (pl.iy * w), r.z * (pl.iz * w));
+        }
+    }
+
+    // ---- directional light with cascaded shadow maps (pbr.frag:163-183, basic.vert:45-48)
+    // (a surface facing away from the light gets max(N.L, 0) = 0 from it: no cascade look-up, no BRDF)
+    const F3 dirL = f3(fr.dir_L[0], fr.dir_L[1], fr.dir_L[2]);
+    const float dir_nl = dot3f(N, dirL);
+    if (fr.lights_set && !(RDR_DIAG & 2) && dir_nl > 0.0f) {
+#pragma clang fp contract(off)  // the light-space coordinates choose the cascade and are compared with stored depths
+        const int ncasc = (int)fr.n_cascades, res = (int)fr.dir_res;
+        int split = 0;
+        float ls0 = 0.0f, ls1 = 0.0f, ls2 = 0.0f;
+        for (; split < ncasc; split++) {
+            const F4 lsp = xform_point(fr.csm_viewproj[split], P.x, P.y, P.z);
+            ls0 = lsp.x * 0.5f + 0.5f; ls1 = lsp.y * 0.5f + 0.5f; ls2 = lsp.z;
+            if (lsp.w != 1.0f) { ls0 /= lsp.w; ls1 /= lsp.w; ls2 /= lsp.w; }
+            if (fminf(ls0, ls1) > 1e-2f && fmaxf(ls0, ls1) < 1.0f - 1e-2f) break;
+        }
+        const int layer = min(split, ncasc - 1);
+        const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * (res + 4) * (res + 4), res, ls0, ls1, ls2);
+        if (shadowTest > 1e-3f) {
+            const F3 r = brdf_eval(bf, 1.0f, dir_nl, dot3f(V, dirL));
+            Lo = Lo + f3(r.x * (fr.dir_I[0] * shadowTest), r.y * (fr.dir_I[1] * shadowTest), r.z * (fr.dir_I[2] * shadowTest));
+        }
+    }
+
+    if (!RDR_IBL_FIRST) image_based();
+    out[0] = fminf(Lo.x, 10.0f);
+    out[1] = fminf(Lo.y, 10.0f);
+    out[2] = fminf(Lo.z, 10.0f);
     out[3] = (MASKED && mt.alpha_mode == 1) ? 1.0f : albedo[3];
 }
 
