@@ -52,6 +52,37 @@ def measured_traffic(kernel):
     return best
 
 
+def measured_valu(kernel):
+    """Measured VALU figures of `kernel` from the newest profiles/*valu.json (written by tools/valu_summary.py from the
+    PMC passes of this same bench command): wave-instructions per launch and the share of SIMD cycles that issued one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*valu.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    e = d.get(kernel)
+    if e:
+        e = dict(e, source=os.path.basename(files[-1]))
+    return e
+
+
+def launch_ranks(n):
+    """`--gpus N` without a launcher around it: starts N fresh ranks (one per GPU) under torch.distributed.run as a
+    child process, before this process has touched a GPU, and exits with the child's status."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; refusing to report a {n}-GPU number from fewer")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
 def camera_for_frame(r, k):
     """Camera path down the hall; frame k of the job."""
     t = (k % 240) / 240.0
@@ -69,16 +100,18 @@ def main():
     ap.add_argument("--tex", type=int, default=1024)
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--diag-lights", type=int, default=-1, help="diagnostic only: keep the first N point lights (not the benchmark workload)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a.gpus)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: every rank of the job must be started (one per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path")
     torch.cuda.set_device(local_rank)
@@ -132,10 +165,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    per_rank = [[elapsed, float(sharder.frames_rendered - a.warmup), sharder.gather_wait_s]]
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device="cuda")
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        per_rank = [p.tolist() for p in parts]
+        elapsed = max(p[0] for p in per_rank)
+    if len(per_rank) != a.gpus or any(p[1] != a.steps for p in per_rank):
+        raise SystemExit(f"expected {a.gpus} ranks with {a.steps} timed frames each, saw {[(p[1]) for p in per_rank]}")
     last_stats = last_stats[0]
 
     cpu_baseline = None
@@ -147,14 +185,20 @@ def main():
         scenes.sponza_like(ro, tex_size=a.tex, detail=a.detail)
         camera_for_frame(ro, 0)
         ro.render_frame(exposure_mode=1, temporal_luminance=0.5)  # warm-up (renders the static point-shadow maps too)
-        times = []
+        times, passes = [], []
         for k in range(a.cpu_frames):
             camera_for_frame(ro, 1 + k)
             tc = time.perf_counter()
             ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
             times.append(time.perf_counter() - tc)
-        cpu_baseline = {"value": 1.0 / float(np.median(times)), "unit": "frames/s", "cores": cores, "kind": "port",
-                        "sample": f"{a.cpu_frames} frames of the same {W}x{H} workload after 1 warm-up, OpenMP CPU restatement (not lavapipe)"}
+            so = ro.frame_stats()
+            passes.append((so.ms_geometry, so.ms_shade, so.ms_bloom))
+        mid = int(np.argsort(times)[len(times) // 2])  # the median frame
+        cpu_baseline = {"value": 1.0 / float(times[mid]), "unit": "frames/s", "cores": cores, "kind": "port",
+                        "sample": f"median of {a.cpu_frames} frames of the same {W}x{H} workload after 1 warm-up, OpenMP CPU restatement (not lavapipe)",
+                        "ms_per_pass": {"shadow + main raster": passes[mid][0], "shading + blended pass": passes[mid][1],
+                                        "bloom + tonemap + luminance": passes[mid][2]},
+                        "frame_ms_all": [round(t * 1e3, 1) for t in times]}
         ro.close()
 
     if rank == 0:
@@ -185,7 +229,7 @@ def main():
                        "lavapipe_oracle": "not available; CPU restatement used"},
             "roofline": {"kernel": "k_shade_opaque", "bound": "valu_fp32", "achieved": shade_tf, "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": shade_tf / VALU_FP32_PEAK_TF, "traffic": measured_traffic("k_shade_opaque<4>"), "ms": shade_ms,
-                         "algorithmic": f"{shade_flops_per_px(n_lights):.0f} flop/px x {n_px} px"},
+                         "algorithmic": f"{shade_flops_per_px(n_lights):.0f} flop/px x {n_px} px", "valu_measured": measured_valu("k_shade_opaque<4>")},
             "roofline_passes": [
                 {"pass": "bloom chain + tonemap + luminance", "bound": "hbm", "achieved": post_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": post_gbs / HBM_PEAK_GBS, "ms": post_ms, "algorithmic": f"{POST_BYTES_PER_PX} B/px x {n_px} px"},
@@ -193,6 +237,8 @@ def main():
             "device_ms": {k: v / K for k, v in acc.items()},
             "frame_counters": {"triangle_instances": int(last_stats.triangle_instances), "triangles_binned": int(last_stats.triangles_binned),
                                "tile_pairs": int(last_stats.tile_pairs), "views": int(last_stats.views)},
+            "ranks_seen": len(per_rank),
+            "per_rank": [{"frames_per_s": p[1] / p[0], "gather_wait_ms_per_frame": p[2] * 1e3 / max(p[1] + a.warmup, 1.0)} for p in per_rank],
             "scene_build_s": build_s,
             "cpu_baseline": cpu_baseline,
         }

@@ -42,11 +42,11 @@ typedef struct rdr_ctx rdr_ctx;
 /* Mirrors RendererSettings (Renderer/VulkanRenderer.h:44-59) field for field;
  * bools widened to uint32_t so the struct has no padding surprises. */
 typedef struct rdr_settings {
-    uint32_t hdr_output_enabled;               /* ignored: output is 8-bit UNORM */
+    uint32_t hdr_output_enabled;               /* must be 0: the output is 8-bit UNORM; rdr_create refuses 1 with RDR_ERR_UNSUPPORTED */
     uint32_t dynamic_shadows_enabled;          /* default 1   */
-    uint32_t point_shadow_map_resolution;      /* default 512 */
-    uint32_t point_shadow_map_count;           /* default 8   */
-    uint32_t directional_shadow_map_resolution;/* default 2048 */
+    uint32_t point_shadow_map_resolution;      /* default 512;  1 .. 8192  */
+    uint32_t point_shadow_map_count;           /* default 8;    0 .. 64    */
+    uint32_t directional_shadow_map_resolution;/* default 2048; 1 .. 16384 */
     uint32_t directional_shadow_cascade_levels;/* default 4 (max 4) */
     uint32_t vsync;                            /* ignored (headless) */
     float exposure_bias;                       /* default 0   */
@@ -216,6 +216,9 @@ typedef struct rdr_frame_stats {
                                    * view (their triangles skip set-up); 0 from the CPU checker, which has no such
                                    * pre-pass. The reference culls whole primitives only (VulkanRenderer.cpp:929-943). */
     uint64_t frame_index;         /* which rdr_render_frame call of this context these numbers belong to, counted from 1 */
+    uint32_t blend_groups;        /* 0: the blended pass ran over all tiles at once; n > 0: its fragment list would have exceeded
+                                   * the context's budget and the tiles were rendered in n groups (same result, bounded memory) */
+    float host_ms;                /* host time rdr_render_frame spent building and enqueueing this frame (culling, ordering, uploads) */
 } rdr_frame_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

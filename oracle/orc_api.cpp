@@ -4,6 +4,7 @@
 // (include/rdr.h), plus the host side of the frame: camera matrices, frustum
 // culling and draw ordering, shadow-view set-up, exposure.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -293,6 +294,12 @@ int orc_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     if (!settings || !out || width == 0 || height == 0) return RDR_ERR_INVALID;
     if ((settings->msaa != 1 && settings->msaa != 4) || settings->directional_shadow_cascade_levels < 1 || settings->directional_shadow_cascade_levels > 4)
         return RDR_ERR_UNSUPPORTED;
+    // what the implementation does not offer is refused, not ignored: an HDR output image (VulkanRenderer.h:45), shadow
+    // maps whose tile boxes would not fit 16-bit coordinates, more cube slots than a frame can reasonably hold
+    if (settings->hdr_output_enabled) return RDR_ERR_UNSUPPORTED;
+    if (settings->directional_shadow_map_resolution == 0 || settings->point_shadow_map_resolution == 0) return RDR_ERR_INVALID;
+    if (settings->directional_shadow_map_resolution > 16384 || settings->point_shadow_map_resolution > 8192 || settings->point_shadow_map_count > 64)
+        return RDR_ERR_UNSUPPORTED;
     rdr_ctx* c = new (std::nothrow) rdr_ctx();
     if (!c) return RDR_ERR_DEVICE;
     c->settings = *settings; c->W = width; c->H = height;
@@ -351,6 +358,7 @@ int orc_make_texture(rdr_ctx* c, uint32_t image, const rdr_sampler* s, uint32_t*
     if (!c || !s || !out_id || image >= c->images.size()) return fail(c, RDR_ERR_INVALID, "make_texture: bad argument");
     if (s->mag_filter != RDR_FILTER_LINEAR || s->min_filter != RDR_FILTER_LINEAR || s->mipmap_filter != RDR_FILTER_LINEAR)
         return fail(c, RDR_ERR_UNSUPPORTED, "make_texture: only LINEAR filters are supported");
+    if (s->wrap_u > RDR_WRAP_CLAMP || s->wrap_v > RDR_WRAP_CLAMP) return fail(c, RDR_ERR_INVALID, "make_texture: bad wrap mode");
     c->textures.push_back(Texture{image, *s});
     *out_id = (uint32_t)c->textures.size() - 1;
     return RDR_OK;
@@ -639,12 +647,22 @@ static float compute_exposure(Ctx& c, const rdr_frame_params* fp) {
     return exposure;
 }
 
-int orc_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int, float* out_avg) {
+// Frames are rendered to completion, one at a time. What the HIP library promises a caller that keeps two frames in
+// flight (include/rdr.h, rdr_render_frame) is reproduced for the statistics: after a call with a "device" destination
+// (here simply memory) rdr_get_frame_stats still describes the frame before it, until the next frame or a synchronize.
+int orc_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int out_is_device, float* out_avg) {
     if (!c) return RDR_ERR_INVALID;
+    if (c->stats_deferred) { c->done_stats = c->stats; c->stats_deferred = false; }
     const uint32_t W = c->W, H = c->H, S = c->settings.msaa;
-    const uint64_t frame_index = c->stats.frame_index + 1;  // frames are rendered to completion, one at a time
+    const uint64_t frame_index = c->stats.frame_index + 1;
     c->stats = rdr_frame_stats{};
     c->stats.frame_index = frame_index;
+    // per-pass wall-clock times of this CPU run (what bench.py reports beside the GPU's pass times)
+    const auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto ms_between = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<float, std::milli>(b - a).count();
+    };
+    const auto t_begin = now();
     const V3 cam_pos = c->camera.position;
     const M4 viewproj = c->camera.viewProj();
     if (c->lights_set) {
@@ -662,18 +680,30 @@ int orc_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     RasterTarget rt{W, H, S, c->depth.data(), c->vis.data()};
     raster_draws(*c, od, rt, CULL_BACK, &c->stats.triangle_instances, &c->stats.triangles_binned);
     c->stats.views++;
+    const auto t_geometry = now();
     shade_main(*c, od, bd, viewproj, cam_pos);
+    const auto t_shade = now();
     const float exposure = compute_exposure(*c, fp);
     bloom_and_tonemap(*c, exposure);
     const float avg = average_luminance(*c);
+    const auto t_post = now();
+    c->stats.ms_geometry = ms_between(t_begin, t_geometry);
+    c->stats.ms_shade = ms_between(t_geometry, t_shade);
+    c->stats.ms_bloom = ms_between(t_shade, t_post);  // bloom chain + tonemap + luminance are one function here
+    c->stats.ms_total = ms_between(t_begin, t_post);
     c->last_avg_log_lum = avg;
     c->stats.exposure = exposure; c->stats.avg_log_luminance = avg;
     if (out_rgba8) std::memcpy(out_rgba8, c->out.data(), c->out.size());
     if (out_avg) *out_avg = avg;
+    if (out_is_device && out_rgba8) c->stats_deferred = true;
+    else c->done_stats = c->stats;
     return RDR_OK;
 }
-int orc_synchronize(rdr_ctx*) { return RDR_OK; }
-int orc_get_frame_stats(rdr_ctx* c, rdr_frame_stats* out) { if (!c || !out) return RDR_ERR_INVALID; *out = c->stats; return RDR_OK; }
+int orc_synchronize(rdr_ctx* c) {
+    if (c && c->stats_deferred) { c->done_stats = c->stats; c->stats_deferred = false; }
+    return RDR_OK;
+}
+int orc_get_frame_stats(rdr_ctx* c, rdr_frame_stats* out) { if (!c || !out) return RDR_ERR_INVALID; *out = c->done_stats; return RDR_OK; }
 
 int orc_read_depth(rdr_ctx* c, float* out) { if (!c || !out || c->depth.empty()) return RDR_ERR_INVALID; std::memcpy(out, c->depth.data(), c->depth.size() * 4); return RDR_OK; }
 int orc_read_visibility(rdr_ctx* c, uint32_t* out) { if (!c || !out || c->vis.empty()) return RDR_ERR_INVALID; std::memcpy(out, c->vis.data(), c->vis.size() * 4); return RDR_OK; }

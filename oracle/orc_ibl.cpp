@@ -4,9 +4,10 @@
 // (Renderer/VulkanRendererEnvironment.cpp:193-250 irradiance, :324-391
 // GGX prefilter; shaders envbake.vert, envbakediffuse.frag,
 // envbakespecular.frag). Cube face selection and face coordinates follow the
-// Vulkan 1.3 "Cube Map Face Selection" tables; filtering is bilinear inside
-// the selected face with clamp-to-edge (no cross-face taps), the same choice
-// as the HIP path.
+// Vulkan 1.3 "Cube Map Face Selection" tables; filtering is bilinear and
+// seamless: a footprint texel that falls outside the selected face is the texel
+// across the shared cube edge (cube_fold below; at a corner the row index is
+// clamped first), the same choice as the HIP path.
 #include <algorithm>
 #include <cmath>
 

@@ -129,7 +129,9 @@ struct Ctx {
 
     float temporal_luminance = 0.0f;
     float last_avg_log_lum = 0.0f;
-    rdr_frame_stats stats{};
+    rdr_frame_stats stats{};       // of the frame rendered last
+    rdr_frame_stats done_stats{};  // what rdr_get_frame_stats hands out (see orc_render_frame)
+    bool stats_deferred = false;
 };
 
 // orc_post.cpp

@@ -49,8 +49,11 @@ void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DPo
 #define RDR_FRAG_RUN 128u
 #define RDR_BLEND_SHADE_BLOCKS 2048u
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DView* view, const DShadeTri* tris, const DTriRec* recs,
-                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
+                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t tile0, uint32_t n_tiles, void* color,
                          void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity);
+// dry run of the collect pass over all tiles: tile_slots[tile] = list slots the tile would take (0 for tiles without blended triangles; zero the array first)
+void launch_blend_count(hipStream_t s, int samples, const DView* view, const DTriRec* recs, const uint32_t* sorted_vals, const uint32_t* tile_start,
+                        const uint32_t* tile_end, uint32_t n_tiles, uint32_t* tile_slots);
 
 // kernels_ibl.hip
 // per-frame skinning of the vertex arena (kernels_skin.hip): rest pose + joints/weights + palette -> pos/attr

@@ -644,20 +644,31 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
 //   k_blend_shade    one lane per list slot, any order: shades the fragment, stores its colour.
 //   k_blend_resolve  one lane per pixel of the tiles with blended triangles: walks the pixel's chain in order,
 //                    blends into the sample colours the opaque pass left, resolves.
-template <int S>
+//
+// COUNT: a dry run of the same walk that writes nothing but tile_slots[tile] = the list slots the tile's waves would
+// take (whole runs, exactly as the real pass hands them out). The host uses it when the upper bound it has for the
+// list is larger than it is willing to allocate: it then cuts the tiles into groups whose slots fit the list and runs
+// collect / shade / resolve once per group (`tile0` = first tile of the group), so that any number of blended layers
+// is rendered in bounded memory.
+template <int S, bool COUNT>
 __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__ views, const DTriRec* __restrict__ recs,
                                                        const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
                                                        const uint32_t* __restrict__ tile_end, uint4* __restrict__ frags,
-                                                       uint32_t* __restrict__ frag_head, uint32_t* __restrict__ frag_used, uint32_t capacity) {
+                                                       uint32_t* __restrict__ frag_head, uint32_t* __restrict__ frag_used, uint32_t capacity,
+                                                       uint32_t tile0, uint32_t* __restrict__ tile_slots) {
     __shared__ uint32_t lds_rec[BLEND_CHUNK * 32];
     __shared__ uint32_t lds_ids[BLEND_CHUNK];
     __shared__ uint32_t lds_mode[BLEND_CHUNK];  // RASTER_LOCAL32: the record was rewritten with 32-bit tile-local edge functions
     __shared__ uint32_t lds_first_run;
     const DView vw = views[0];  // the blended view of the batch; its tile lists start at tile_base
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = tile0 + blockIdx.x;
     const uint32_t begin = tile_start[vw.tile_base + tile], end = tile_end[vw.tile_base + tile];
     if (begin >= end) return;
-    if (threadIdx.x == 0) lds_first_run = atomicAdd(frag_used, 4u * RDR_FRAG_RUN);
+    if (threadIdx.x == 0) {
+        if (COUNT) { lds_first_run = 0u; tile_slots[tile] = 4u * RDR_FRAG_RUN; }
+        else lds_first_run = atomicAdd(frag_used, 4u * RDR_FRAG_RUN);
+    }
+    uint32_t extra_runs = 0;  // COUNT: runs this wave takes beyond its first
     const int tx = (int)(tile % vw.tiles_x), ty = (int)(tile / vw.tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qx0 = tx * RDR_TILE + (wave & 1) * 8, qy0 = ty * RDR_TILE + (wave >> 1) * 8;
@@ -745,6 +756,11 @@ __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__
             const unsigned long long pm = __ballot(pass != 0u);
             if (!pm) continue;
             const uint32_t want = (uint32_t)__popcll(pm);
+            if (COUNT) {
+                if (run_at + want > run_end) { extra_runs++; run_at = 0u; run_end = RDR_FRAG_RUN; }
+                run_at += want;
+                continue;
+            }
             if (run_at + want > run_end) {  // this run cannot take them: mark what is left of it empty, take another
                 if (run_at + (uint32_t)lane < run_end) frags[run_at + lane] = make_uint4(BLEND_NONE, 0u, 0u, BLEND_NONE);
                 if (run_at + 64u + (uint32_t)lane < run_end) frags[run_at + 64u + lane] = make_uint4(BLEND_NONE, 0u, 0u, BLEND_NONE);
@@ -761,6 +777,11 @@ __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__
             }
             run_at += want;
         }
+    }
+    if (COUNT) {
+        __syncthreads();  // behind thread 0's store of the four first runs
+        if (lane == 0 && extra_runs) atomicAdd(&tile_slots[tile], extra_runs * RDR_FRAG_RUN);
+        return;
     }
     // the unused tail of the wave's last run
     if (have_run && run_end <= capacity) {
@@ -796,9 +817,9 @@ template <int S>
 __global__ void __launch_bounds__(256) k_blend_resolve(const DView* __restrict__ views, const uint32_t* __restrict__ tile_start,
                                                        const uint32_t* __restrict__ tile_end, const uint4* __restrict__ frags,
                                                        const float4* __restrict__ frag_col, const uint32_t* __restrict__ frag_head,
-                                                       const uint2* __restrict__ color, uint2* __restrict__ hdr) {
+                                                       const uint2* __restrict__ color, uint2* __restrict__ hdr, uint32_t tile0) {
     const DView vw = views[0];
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = tile0 + blockIdx.x;
     if (tile_start[vw.tile_base + tile] >= tile_end[vw.tile_base + tile]) return;
     const int px = (int)(tile % vw.tiles_x) * RDR_TILE + ((int)threadIdx.x & 15), py = (int)(tile / vw.tiles_x) * RDR_TILE + ((int)threadIdx.x >> 4);
     if (px >= (int)vw.w || py >= (int)vw.h) return;
@@ -851,20 +872,30 @@ void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DPo
         hipLaunchKernelGGL(k_shade_opaque<4>, dim3(grid), dim3(256), 0, s, fr, lights, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
 }
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DView* view, const DShadeTri* tris, const DTriRec* recs,
-                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t n_tiles, void* color,
+                         const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t tile0, uint32_t n_tiles, void* color,
                          void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity) {
     if (!n_tiles) return;
     if (samples == 1)
-        hipLaunchKernelGGL(k_blend_collect<1>, dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
-                           frag_used, capacity);
+        hipLaunchKernelGGL((k_blend_collect<1, false>), dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
+                           frag_used, capacity, tile0, (uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL(k_blend_collect<4>, dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
-                           frag_used, capacity);
+        hipLaunchKernelGGL((k_blend_collect<4, false>), dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
+                           frag_used, capacity, tile0, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_blend_shade, dim3(RDR_BLEND_SHADE_BLOCKS), dim3(256), 0, s, fr, lights, tris, (const uint4*)frags, (float4*)frag_col, frag_used, capacity);
     if (samples == 1)
         hipLaunchKernelGGL(k_blend_resolve<1>, dim3(n_tiles), dim3(256), 0, s, view, tile_start, tile_end, (const uint4*)frags, (const float4*)frag_col,
-                           frag_head, (const uint2*)color, (uint2*)hdr);
+                           frag_head, (const uint2*)color, (uint2*)hdr, tile0);
     else
         hipLaunchKernelGGL(k_blend_resolve<4>, dim3(n_tiles), dim3(256), 0, s, view, tile_start, tile_end, (const uint4*)frags, (const float4*)frag_col,
-                           frag_head, (const uint2*)color, (uint2*)hdr);
+                           frag_head, (const uint2*)color, (uint2*)hdr, tile0);
+}
+void launch_blend_count(hipStream_t s, int samples, const DView* view, const DTriRec* recs, const uint32_t* sorted_vals, const uint32_t* tile_start,
+                        const uint32_t* tile_end, uint32_t n_tiles, uint32_t* tile_slots) {
+    if (!n_tiles) return;
+    if (samples == 1)
+        hipLaunchKernelGGL((k_blend_collect<1, true>), dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)nullptr,
+                           (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, tile_slots);
+    else
+        hipLaunchKernelGGL((k_blend_collect<4, true>), dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)nullptr,
+                           (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u, tile_slots);
 }

@@ -8,9 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <new>
 #include <string>
@@ -181,10 +183,12 @@ struct rdr_ctx {
     std::vector<DDraw> main_draws;  // opaque draws of the last frame (kept for read-backs)
     uint32_t batch_instances = 0;   // triangle instances of the last raster batch
     uint64_t blend_pairs = 0, blend_box_pixels = 0;  // of the last batch: (triangle, tile) pairs / box pixels of blended-view triangles
-    DevBuf d_frags, d_frag_col, d_frag_head;  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
+    DevBuf d_frags, d_frag_col, d_frag_head, d_tile_slots;
+    uint64_t blend_budget_slots = 48ull << 20;  // fragment-list slots (32 B each) a frame may use at once; RDR_BLEND_BUDGET_SLOTS overrides (tests)  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
 
     bool point_borders_stale = false;   // a face of a point-light cube was (or is about to be) re-rendered: the borders follow
     uint32_t point_cubes_in_use = 0;
+    double host_wait_s = 0.0;           // time the current rdr_render_frame call has spent blocked on the GPU
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     // Two frames can be in flight: a frame rendered into a device destination is only enqueued, and the next call builds
     // and enqueues its first half while the GPU still works on this one. Each keeps its own events and its own block
@@ -216,6 +220,8 @@ struct rdr_ctx {
 };
 
 namespace {
+
+double host_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fail(rdr_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 int hip_fail(rdr_ctx* c, const char* what, hipError_t e) {
@@ -556,7 +562,11 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + RDR_READ_MID, counters, RDR_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_pairs, c->stream));
     if (after_scan) RDR_TRY(after_scan());
-    HIP_TRY(hipEventSynchronize(c->ev_pairs));
+    {
+        const double t_wait = host_now();
+        HIP_TRY(hipEventSynchronize(c->ev_pairs));
+        c->host_wait_s += host_now() - t_wait;
+    }
     const uint32_t* mid = (const uint32_t*)(c->h_read.as<uint8_t>() + RDR_READ_MID);
     const uint32_t n_pairs = mid[0];
     // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
@@ -873,6 +883,12 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     if ((settings->msaa != 1 && settings->msaa != 4) || settings->directional_shadow_cascade_levels < 1 ||
         settings->directional_shadow_cascade_levels > RDR_MAX_CASCADES)
         return RDR_ERR_UNSUPPORTED;
+    // what the implementation does not offer is refused, not ignored: an HDR output image (VulkanRenderer.h:45), shadow
+    // maps whose tile boxes would not fit 16-bit coordinates, more cube slots than a frame can reasonably hold
+    if (settings->hdr_output_enabled) return RDR_ERR_UNSUPPORTED;
+    if (settings->directional_shadow_map_resolution == 0 || settings->point_shadow_map_resolution == 0) return RDR_ERR_INVALID;
+    if (settings->directional_shadow_map_resolution > 16384 || settings->point_shadow_map_resolution > 8192 || settings->point_shadow_map_count > 64)
+        return RDR_ERR_UNSUPPORTED;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RDR_ERR_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return RDR_ERR_DEVICE;
@@ -901,6 +917,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     // this device's copy of the no-allocation scratch array (the device is current: hipSetDevice above)
     ok = ok && hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch)) == hipSuccess && c->noalloc_scratch != nullptr;
     if (!ok) { rdr_destroy(c); return RDR_ERR_DEVICE; }
+    if (const char* e = getenv("RDR_BLEND_BUDGET_SLOTS")) { const long long v = atoll(e); if (v > 0) c->blend_budget_slots = (uint64_t)v; }
     c->camera.type = 0;  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
     c->camera.position = make3(0, 0, 0); c->camera.euler = make3(0, 0, 0);
     c->camera.near_plane = 0.1f; c->camera.far_plane = 60.0f;
@@ -929,7 +946,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_env_b, &c->d_irradiance_b, &c->d_prefiltered_b, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
                       &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
-                      &c->d_counters, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_counters, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     DevBuf* alts[] = {&c->alt.batch_tables, &c->alt.frame, &c->alt.shade_tris, &c->alt.recs, &c->alt.keys[0], &c->alt.keys[1], &c->alt.vals[0],
@@ -1375,8 +1392,9 @@ int rdr_set_exposure_bias(rdr_ctx* c, float bias, float gamma) {
     return RDR_OK;
 }
 
-int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int out_is_device, float* out_avg) {
-    if (!c) return RDR_ERR_INVALID;
+static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int out_is_device, float* out_avg) {
+    const double t_enter = host_now();
+    c->host_wait_s = 0.0;
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t W = c->W, H = c->H, S = c->settings.msaa;
     const size_t n = (size_t)W * H;
@@ -1525,20 +1543,57 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         // one run per wave; a wave moves to a fresh run only when fewer than 64 slots are left in its run, so the runs
         // it leaves behind are at least half full; fragments are at most the pixels of the triangles' boxes.
         const uint64_t blocks = std::min<uint64_t>(n_tiles, c->blend_pairs);
-        const uint64_t capacity = blocks * 4u * RDR_FRAG_RUN + 2u * c->blend_box_pixels + RDR_FRAG_RUN;
-        if (capacity >= (1ull << 31)) return fail(c, RDR_ERR_CAPACITY, "blended pass: the fragment list would need more than 2^31 slots");
-        HIP_TRY(c->d_frags.ensure(capacity * 16));
-        HIP_TRY(c->d_frag_col.ensure(capacity * 16));
+        const uint64_t bound = blocks * 4u * RDR_FRAG_RUN + 2u * c->blend_box_pixels + RDR_FRAG_RUN;
         HIP_TRY(c->d_frag_head.ensure(n * 4));
-        launch_raster_blend(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), c->d_views.as<DView>() + (main_view + 1), tris_blend,
-                            c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
-                            c->d_tile_end.as<uint32_t>(), n_tiles, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p, c->d_frag_col.p,
-                            c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, (uint32_t)capacity);
+        auto run_group = [&](uint32_t tile0, uint32_t count, uint32_t capacity) {
+            launch_raster_blend(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), c->d_views.as<DView>() + (main_view + 1),
+                                tris_blend, c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
+                                c->d_tile_end.as<uint32_t>(), tile0, count, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p,
+                                c->d_frag_col.p, c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, capacity);
+        };
+        if (bound <= c->blend_budget_slots) {
+            HIP_TRY(c->d_frags.ensure(bound * 16));
+            HIP_TRY(c->d_frag_col.ensure(bound * 16));
+            run_group(0u, n_tiles, (uint32_t)bound);
+        } else {
+            // The bound is more than this context allocates for the list (many screen-filling layers: the bound counts
+            // every triangle's whole box): a dry run counts the slots each tile really takes, and the tiles are then
+            // rendered in groups that fit the list, one collect / shade / resolve sequence per group. Blending is per
+            // pixel, so the order of the groups does not matter.
+            HIP_TRY(c->d_tile_slots.ensure((size_t)n_tiles * 4));
+            HIP_TRY(hipMemsetAsync(c->d_tile_slots.p, 0, (size_t)n_tiles * 4, c->stream2));
+            launch_blend_count(c->stream2, (int)S, c->d_views.as<DView>() + (main_view + 1), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                               c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, c->d_tile_slots.as<uint32_t>());
+            std::vector<uint32_t> slots(n_tiles);
+            HIP_TRY(hipMemcpyAsync(slots.data(), c->d_tile_slots.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, c->stream2));
+            HIP_TRY(hipStreamSynchronize(c->stream2));
+            uint64_t largest = 0;
+            for (uint32_t t = 0; t < n_tiles; t++) largest = std::max<uint64_t>(largest, slots[t]);
+            const uint64_t list = std::max<uint64_t>(c->blend_budget_slots, largest) + RDR_FRAG_RUN;
+            if (list >= (1ull << 31)) return fail(c, RDR_ERR_CAPACITY, "blended pass: one 16x16 tile alone needs more than 2^31 fragment slots");
+            HIP_TRY(c->d_frags.ensure(list * 16));
+            HIP_TRY(c->d_frag_col.ensure(list * 16));
+            for (uint32_t t0 = 0; t0 < n_tiles;) {
+                uint64_t sum = 0;
+                uint32_t t1 = t0;
+                while (t1 < n_tiles && (t1 == t0 || sum + slots[t1] <= c->blend_budget_slots)) sum += slots[t1++];
+                if (sum) {
+                    if (t0) HIP_TRY(hipMemsetAsync(frame_counters(c) + RDR_COUNTER_FRAGS, 0, 4, c->stream2));
+                    run_group(t0, t1 - t0, (uint32_t)list);
+                    c->stats.blend_groups++;
+                }
+                t0 = t1;
+            }
+        }
         HIP_TRY(hipGetLastError());
     }
 
     // ---- bloom, tonemap, luminance
-    if (c->have_frame && (!fp || fp->exposure_mode == 0)) RDR_TRY(rdr_synchronize(c));  // previous frame's luminance
+    if (c->have_frame && (!fp || fp->exposure_mode == 0)) {  // previous frame's luminance
+        const double t_wait = host_now();
+        RDR_TRY(rdr_synchronize(c));
+        c->host_wait_s += host_now() - t_wait;
+    }
     const float exposure = compute_exposure(c, fp);
     // a device destination receives the frame straight from the tonemap kernel (its 8-byte stores need the alignment)
     uint32_t* direct_out = (out_rgba8 && out_is_device && ((uintptr_t)out_rgba8 & 7u) == 0) ? (uint32_t*)out_rgba8 : nullptr;
@@ -1555,6 +1610,8 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     if (out_rgba8 && !direct_out)
         HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream4));
     HIP_TRY(hipEventRecord(c->ev[5], c->stream4));
+    // host time of this frame: everything this call did up to here, less the time it sat waiting for the GPU
+    c->stats.host_ms = (float)((host_now() - t_enter - c->host_wait_s) * 1e3);
     c->pending[c->slot].on = true;
     c->pending[c->slot].host = c->stats;
     // The frame before this one has had the whole set-up of this one to finish its tail: its results are picked up
@@ -1569,6 +1626,24 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
     RDR_TRY(rdr_synchronize(c));
     if (out_avg) *out_avg = c->last_avg_log_lum;
     return RDR_OK;
+}
+
+int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int out_is_device, float* out_avg) {
+    if (!c) return RDR_ERR_INVALID;
+    const int rc = render_frame_impl(c, fp, out_rgba8, out_is_device, out_avg);
+    if (rc != RDR_OK) {
+        // The frame failed part-way (a buffer could not grow, a capacity limit): what it had enqueued is drained and
+        // it is dropped, so that the context is left as between two frames. An older frame still in flight keeps its
+        // results; the failed frame's index is not reused.
+        const std::string keep = c->err;
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream3);
+        (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream4);
+        (void)hipGetLastError();
+        c->pending[c->slot].on = false;
+        harvest(c, c->slot ^ 1);
+        c->err = keep;
+    }
+    return rc;
 }
 
 int rdr_synchronize(rdr_ctx* c) {

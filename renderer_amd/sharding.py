@@ -42,9 +42,13 @@ class FrameSharder:
     dist      : the initialised torch.distributed module, or None for a single process
     device    : torch device of the staging tensors ("cuda:N" with nccl, "cpu" with gloo)
     depth     : staging slots; depth-1 gathers can be in flight while a frame renders
+    pipelined : keep two frames in flight on the renderer (a frame is only enqueued; its results are collected once the
+                next one has been enqueued behind it). Default: on for device staging tensors, off for host ones.
+    After `run`, `gather_wait_s` is the time this rank spent waiting for gathers it had issued (rank 0: for the frames
+    of all ranks to arrive) and `frames_rendered` the frames it rendered itself.
     """
 
-    def __init__(self, renderer, dist=None, device="cpu", depth=2):
+    def __init__(self, renderer, dist=None, device="cpu", depth=2, pipelined=None):
         import torch
         self.torch = torch
         self.r = renderer
@@ -52,6 +56,9 @@ class FrameSharder:
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
         self.device = torch.device(device)
+        self.pipelined = (self.device.type == "cuda") if pipelined is None else bool(pipelined)
+        self.gather_wait_s = 0.0
+        self.frames_rendered = 0
         self.depth = max(1, int(depth))
         H, W = renderer.height, renderer.width
         self.slots = [torch.empty((H, W, 4), dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
@@ -67,7 +74,8 @@ class FrameSharder:
         """Renders into `tensor`. A device tensor only gets the frame enqueued (returns None: the frame's results are
         picked up by `_collect` once the next frame has been enqueued behind it, or after `synchronize`); a host
         tensor is rendered to completion and its average log-luminance returned."""
-        if tensor.is_cuda:
+        self.frames_rendered += 1
+        if self.pipelined:
             self.r.render_frame(device_ptr=tensor.data_ptr(), **frame_params)
             return None
         out = tensor.numpy()
@@ -88,11 +96,14 @@ class FrameSharder:
             return
         work, rnd, n_valid = self.pending[slot]
         if work is not None:
+            import time
+            t0 = time.perf_counter()
             work.wait()
             if self.device.type == "cuda":
                 # wait() only orders torch's current stream behind the gather; the renderer writes this slot from its
                 # own stream, so the host makes sure the gather (issued a frame ago) has really finished
                 self.torch.cuda.current_stream(self.device).synchronize()
+            self.gather_wait_s += time.perf_counter() - t0
         self.pending[slot] = None
         if on_frames is not None and self.rank == 0:
             imgs = self.recv[slot] if self.recv is not None else [self.slots[slot]]
@@ -107,7 +118,7 @@ class FrameSharder:
         this rank."""
         frame_params = dict(frame_params or {})
         n_rounds = rounds(n_frames, self.world)
-        first_index = self.r.frame_stats().frame_index + 1 if self.slots[0].is_cuda else 0  # index of this job's frame 0
+        first_index = self.r.frame_stats().frame_index + 1 if self.pipelined else 0  # index of this job's frame 0
         in_flight = None  # (round, frame) enqueued on the GPU whose results have not been collected yet
 
         def finish(entry):
@@ -130,7 +141,7 @@ class FrameSharder:
             if k < n_frames:
                 set_frame(self.r, k)
                 avg = self._render_into(self.slots[slot], frame_params)
-            if self.slots[slot].is_cuda:
+            if self.pipelined:
                 # two frames in flight: frame k was only enqueued, and by now the frame before it has finished
                 # (a rank without a frame in this round enqueued nothing behind it and has to wait for it)
                 if in_flight is not None:

@@ -88,3 +88,79 @@ def test_struct_layout_matches_the_c_compiler(tmp_path):
         assert got[(cname, "size")] == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def _refusals(api):
+    """What the settings / resource calls refuse, on either library: (description, status) pairs."""
+    out = []
+
+    def create(**kw):
+        s = B.Settings()
+        api.settings_default(C.byref(s))
+        for k, v in kw.items():
+            setattr(s, k, v)
+        ctx = C.c_void_p()
+        rc = api.create(C.byref(s), 64, 64, 0, C.byref(ctx))
+        if rc == 0:
+            api.destroy(ctx)
+        return rc
+    out.append(("hdr output", create(hdr_output_enabled=1)))
+    out.append(("msaa 2", create(msaa=2)))
+    out.append(("5 cascades", create(directional_shadow_cascade_levels=5)))
+    out.append(("cascade resolution 0", create(directional_shadow_map_resolution=0)))
+    out.append(("point resolution 0", create(point_shadow_map_resolution=0)))
+    out.append(("cascade resolution 65536", create(directional_shadow_map_resolution=65536)))
+    out.append(("point resolution 16384", create(point_shadow_map_resolution=16384)))
+    out.append(("1000 point shadow maps", create(point_shadow_map_count=1000)))
+    return out
+
+
+EXPECTED_REFUSALS = [("hdr output", B.RDR_ERR_UNSUPPORTED), ("msaa 2", B.RDR_ERR_UNSUPPORTED), ("5 cascades", B.RDR_ERR_UNSUPPORTED),
+                     ("cascade resolution 0", B.RDR_ERR_INVALID), ("point resolution 0", B.RDR_ERR_INVALID),
+                     ("cascade resolution 65536", B.RDR_ERR_UNSUPPORTED), ("point resolution 16384", B.RDR_ERR_UNSUPPORTED),
+                     ("1000 point shadow maps", B.RDR_ERR_UNSUPPORTED)]
+
+
+def test_settings_the_checker_refuses(orc_capi):
+    """RendererSettings values neither library implements are refused by rdr_create with a status, never silently ignored
+    (VulkanRenderer.h:44-59: hdrOutputEnabled, the shadow-map sizes and counts)."""
+    assert _refusals(orc_capi) == EXPECTED_REFUSALS
+
+
+def test_resources_the_checker_refuses(orc_capi):
+    """NEAREST sampler filters (VulkanRenderer.cpp:363-385) and image formats other than 8-bit RGB(A) (Image.h:5-14)
+    are refused with RDR_ERR_UNSUPPORTED; the 8-bit formats are accepted."""
+    _check_resource_refusals(orc_capi)
+
+
+def _check_resource_refusals(api):
+    import numpy as np
+
+    from renderer_amd.api import Renderer, RendererError, default_settings
+    r = Renderer(api, 32, 32, default_settings(msaa=1))
+    px = np.zeros((4, 4, 4), np.uint8)
+    for fmt in (B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_SRGB):
+        r.load_image(px, fmt)
+    for fmt in (B.FORMAT_R8G8B8_UNORM, B.FORMAT_R8G8B8_SRGB):
+        r.load_image(px[..., :3], fmt)
+    for fmt in (4, 5, 6, 7):  # the 16- and 32-bit float formats of Image.h
+        out = C.c_uint32()
+        buf = np.zeros(4 * 4 * 16, np.uint8)
+        rc = api.load_image(r._ctx, buf.ctypes.data_as(C.c_void_p), buf.size, 4, 4, fmt, 1, C.byref(out))
+        assert rc == B.RDR_ERR_UNSUPPORTED, fmt
+    img = r.load_image(px, B.FORMAT_R8G8B8A8_UNORM)
+    for filt in ((B.FILTER_NEAREST, B.FILTER_LINEAR, B.FILTER_LINEAR), (B.FILTER_LINEAR, B.FILTER_NEAREST, B.FILTER_LINEAR),
+                 (B.FILTER_LINEAR, B.FILTER_LINEAR, B.FILTER_NEAREST)):
+        s = B.Sampler(filt[0], filt[1], filt[2], B.WRAP_REPEAT, B.WRAP_REPEAT)
+        out = C.c_uint32()
+        assert api.make_texture(r._ctx, img, C.byref(s), C.byref(out)) == B.RDR_ERR_UNSUPPORTED
+    s = B.Sampler(B.FILTER_LINEAR, B.FILTER_LINEAR, B.FILTER_LINEAR, 7, B.WRAP_REPEAT)
+    out = C.c_uint32()
+    assert api.make_texture(r._ctx, img, C.byref(s), C.byref(out)) == B.RDR_ERR_INVALID
+    r.close()
+
+
+@pytest.mark.gpu
+def test_settings_and_resources_the_hip_library_refuses(hip_capi):
+    assert _refusals(hip_capi) == EXPECTED_REFUSALS
+    _check_resource_refusals(hip_capi)

@@ -229,3 +229,46 @@ def test_exposure_recurrence_parity(orc_capi, hip_capi):
     tl = 1.0 - np.exp(-steps[0])
     assert abs(exposures[0] - 0.18 / (1.03 - 2.0 / (np.log2(tl + 1.0) + 2.0))) < 1e-3
     assert len({round(e, 4) for e in exposures}) == len(exposures)
+
+
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_blended_pass_in_bounded_memory(orc_capi, hip_capi, msaa, monkeypatch):
+    """Twelve screen-filling translucent layers with a fragment-list budget far below what they need at once
+    (RDR_BLEND_BUDGET_SLOTS, read when the context is created): the library counts the slots each tile takes in a dry
+    run and renders the tiles in groups. The frame must equal, byte for byte, the one rendered with the default budget
+    (all tiles at once), and agree with the CPU checker, which blends in constant memory as the reference does."""
+    W, H = 200, 120
+
+    def build(r):
+        tex = scenes.material_textures(r, 32, 91, tint=(0.9, 0.9, 0.9), alpha=0.25 + 0.5 * scenes.value_noise(32, 5, octaves=2, base=4))
+        r.add_mesh([scenes.upload_primitive(r, scenes.plane(20, 20, 4, 4, uv_scale=4.0), scenes.make_material(tex))])
+        for k in range(12):
+            quad = scenes.plane(400.0, 400.0, 1, 1, uv_scale=60.0) if k % 3 == 2 else scenes.plane(9.0, 6.0, 12, 8, uv_scale=2.0)
+            quad = quad.transformed(scenes.translation(0.05 * k, 1.2, 2.8 - 0.3 * k) @ scenes.rotation_x(np.pi / 2 + 0.03 * k))
+            mode = scenes.B.ALPHA_MASK if k % 4 == 1 else scenes.B.ALPHA_BLEND
+            mat = scenes.make_material(tex, base_color=(0.4 + 0.04 * k, 1.0 - 0.06 * k, 0.6, 0.3 + 0.04 * k), alpha_mode=mode, alpha_cutoff=0.45,
+                                       metallic=0.2, roughness=0.6)
+            r.add_mesh([scenes.upload_primitive(r, quad, mat, scenes.B.UINT16)])
+        r.set_brdf_lut(scenes.brdf_lut(32, 32))
+        r.set_environment_map(scenes.sky_faces(16))
+        r.set_camera(position=(0.0, 1.3, 4.6), euler=(-0.05, 0.0, 0.0))
+        r.set_lights([((1.5, 2.2, 3.5), (30.0, 24.0, 18.0), True)], scenes.default_directional_light())
+
+    frame = dict(exposure_mode=1, temporal_luminance=0.5)
+    ro, r_all = hp.make_pair(orc_capi, hip_capi, W, H, **hp.small_settings(msaa))
+    monkeypatch.setenv("RDR_BLEND_BUDGET_SLOTS", "20000")
+    _, r_groups = hp.make_pair(orc_capi, hip_capi, W, H, **hp.small_settings(msaa))
+    monkeypatch.delenv("RDR_BLEND_BUDGET_SLOTS")
+    for r in (ro, r_all, r_groups):
+        build(r)
+    out_o, _ = ro.render_frame(**frame)
+    out_a, _ = r_all.render_frame(**frame)
+    out_g, _ = r_groups.render_frame(**frame)
+    assert r_all.frame_stats().blend_groups == 0 and r_groups.frame_stats().blend_groups >= 4
+    assert np.array_equal(out_a, out_g), "rendering the blended tiles in groups must not change the frame"
+    assert np.array_equal(r_all.read_hdr(), r_groups.read_hdr()) and np.array_equal(r_all.read_depth(), r_groups.read_depth())
+    assert np.array_equal(ro.read_depth(), r_groups.read_depth())
+    hp.assert_image_close(out_o, out_g)
+    # a second frame on the same context (buffers are reused, counters restart)
+    out_g2, _ = r_groups.render_frame(**frame)
+    assert np.array_equal(out_g2, out_g)
