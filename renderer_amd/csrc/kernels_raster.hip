@@ -347,7 +347,15 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
     const unsigned long long alive = __ballot(count != 0u);
     uint32_t* slot = n_binned + (((blockIdx.x << 2) | (threadIdx.x >> 6)) & (RDR_BINNED_SLOTS - 1u)) * 32u;
     const bool leader = (threadIdx.x & 63u) == 0u;
-    if (alive && leader) atomicAdd(slot, (uint32_t)__popcll(alive));
+    if (alive) {
+        // (triangle, tile) pairs of the wave, summed in 64 bits: the scan that follows works in 32 bits, and the host
+        // refuses the batch when the total would not fit instead of letting it wrap
+        unsigned long long pairs64 = count;
+#pragma unroll
+        for (int dlt = 32; dlt >= 1; dlt >>= 1)
+            pairs64 += ((unsigned long long)(uint32_t)__shfl_xor((int)(pairs64 >> 32), dlt) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)pairs64, dlt);
+        if (leader) { atomicAdd(slot, (uint32_t)__popcll(alive)); atomicAdd((unsigned long long*)(slot + 6), pairs64); }
+    }
     // Triangles of the blended view (load == 2): their (triangle, tile) pairs and the pixels of their boxes bound
     // the fragment list of the blended pass from above; the host sizes that list from these sums.
     const bool blended = count != 0u && blended_view;

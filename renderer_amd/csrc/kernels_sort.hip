@@ -81,8 +81,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(uint32_t* __restrict__
 // itself (block 0 also writes the grand total). With a few hundred tiles that is cheaper than a single-block kernel in
 // between, whose launch and drain cost more than its work.
 template <bool RAW>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ block_sums,
-                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ out_total) {
+// `in` and `out` may be the same array (both callers scan in place): neither is declared restrict.
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* in, uint32_t n, const uint32_t* __restrict__ block_sums,
+                                                           uint32_t* out, uint32_t* __restrict__ out_total) {
     __shared__ uint32_t ws[SCAN_BLOCK / 64];
     const uint32_t base = blockIdx.x * SCAN_TILE;
     uint32_t before = 0;

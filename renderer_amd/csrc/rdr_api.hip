@@ -188,6 +188,7 @@ struct rdr_ctx {
 
     bool point_borders_stale = false;   // a face of a point-light cube was (or is about to be) re-rendered: the borders follow
     uint32_t point_cubes_in_use = 0;
+    unsigned long long frame_pairs_before = 0;  // (triangle, tile) pairs of the batches of this frame binned so far
     double host_wait_s = 0.0;           // time the current rdr_render_frame call has spent blocked on the GPU
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     // Two frames can be in flight: a frame rendered into a device destination is only enqueued, and the next call builds
@@ -571,12 +572,21 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     const uint32_t n_pairs = mid[0];
     // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
     c->blend_pairs = 0; c->blend_box_pixels = 0;
+    unsigned long long pairs64 = 0;
     for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
         const uint32_t* slot = mid + 16 + k * 32;
         c->blend_pairs += slot[1];
         unsigned long long a; memcpy(&a, slot + 2, 8);
         c->blend_box_pixels += a;
+        memcpy(&a, slot + 6, 8);
+        pairs64 += a;
     }
+    // the 32-bit scan total is only valid when the 64-bit sum set-up kept beside it fits (the counters run on over the
+    // batches of a frame: this batch's share is what was added since the batch before)
+    const unsigned long long batch_pairs = pairs64 - c->frame_pairs_before;
+    c->frame_pairs_before = pairs64;
+    if (batch_pairs >= 0xFFFFFFF0ull || batch_pairs != (unsigned long long)n_pairs)
+        return fail(c, RDR_ERR_CAPACITY, "more than 2^32 (triangle, tile) pairs in one batch: too many large triangles over too many views");
     for (int k = 0; k < 2; k++) {
         HIP_TRY(c->d_keys[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
         HIP_TRY(c->d_vals[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
@@ -1419,6 +1429,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     HIP_TRY(c->d_hdr.ensure(n * 8));
     c->stats = rdr_frame_stats{};
     c->stats.frame_index = ++c->frames;
+    c->frame_pairs_before = 0;
     HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_BYTES, c->stream));
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const vec3 cam_pos = c->camera.position;
