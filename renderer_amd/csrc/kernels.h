@@ -14,6 +14,10 @@ struct IrradianceTables {  // sin/cos of the 24 azimuth and 6 polar angles of en
 // kernels_post.hip
 void launch_bloom_down(hipStream_t s, const void* src, bool src_is_hdr, int sw, int sh, uint32_t* dst, int dw, int dh, int dst_pitch);
 void launch_bloom_up(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int dst_pitch);
+// the whole chain before the tonemap kernel (five down-samples, up-samples down to mip 1); level k is max(1, W >> k) x max(1, H >> k)
+// returns true when the accumulated mips 3 and 4 were written to fin3 / fin4 instead of in place
+bool launch_bloom_chain(hipStream_t s, const void* hdr, uint32_t* const mip[6], const int w[6], const int h[6], int W, int H, uint32_t* fin3,
+                        uint32_t* fin4);
 // last up-sample (mip 1 -> mip 0) fused with the tonemap; sw/sh = 0 when the image has no mip 1
 void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* mip1, int sw, int sh, uint32_t* bloom0, uint32_t* out, float* loglum,
                     int W, int H, float scale, float inv_gamma, float white, float log2_6);

@@ -96,6 +96,236 @@ __global__ void __launch_bounds__(256) k_bloom_up(const uint32_t* __restrict__ s
         }
 }
 
+// ---- the same passes with their source tiles staged in LDS -------------------------------------------------------
+//
+// k_bloom_down_lds: a block produces DOWN_TX x DOWN_TY destination texels and first copies the (2 DOWN_TX + 4) x
+// (2 DOWN_TY + 4) source texels its 13-tap footprints cover into LDS, packed as mip texels (for the colour image: read
+// once, truncated to B10G11R11 once, instead of once per tap). Edge clamping happens while staging, so the taps index
+// LDS without tests. Values and the order of the fma chain are those of k_bloom_down: the results are identical.
+#define DOWN_TX 32
+#define DOWN_TY 8
+#define DOWN_SW (2 * DOWN_TX + 4)
+#define DOWN_SH (2 * DOWN_TY + 4)
+
+// 13-tap kernel at LDS position (cx, cy) of a packed tile with row pitch `pitch`
+RDR_DEV uint32_t down13(const uint32_t* tile, int pitch, int cx, int cy) {
+    const int dxs[13] = {+1, +1, -1, -1, -2, 0, +2, +2, +2, 0, -2, -2, 0};
+    const int dys[13] = {+1, -1, +1, -1, -2, -2, -2, 0, +2, +2, +2, 0, 0};
+    const float ws[13] = {0.125f, 0.125f, 0.125f, 0.125f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.125f};
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 13; t++) {
+        float r, g, b;
+        unpack_r11g11b10(tile[(cy + dys[t]) * pitch + cx + dxs[t]], r, g, b);
+        acc0 = fmaf(ws[t], r, acc0); acc1 = fmaf(ws[t], g, acc1); acc2 = fmaf(ws[t], b, acc2);
+    }
+    return pack_r11g11b10(acc0, acc1, acc2);
+}
+
+template <bool FROM_HDR>
+__global__ void __launch_bounds__(256) k_bloom_down_lds(const void* __restrict__ src_v, int sw, int sh, uint32_t* __restrict__ dst,
+                                                        int dw, int dh, int dst_pitch) {
+    __shared__ uint32_t tile[DOWN_SH * DOWN_SW];
+    const int x0 = blockIdx.x * DOWN_TX, y0 = blockIdx.y * DOWN_TY;
+    const int sx0 = 2 * x0 - 2, sy0 = 2 * y0 - 2;
+    for (int i = threadIdx.x; i < DOWN_SH * DOWN_SW; i += 256) {
+        const int ly = i / DOWN_SW, lx = i - ly * DOWN_SW;
+        const int sx = clampi(sx0 + lx, 0, sw - 1), sy = clampi(sy0 + ly, 0, sh - 1);
+        uint32_t p;
+        if (FROM_HDR) {
+            float r, g, b, a;
+            unpack_half4(((const uint2*)src_v)[(size_t)sy * sw + sx], r, g, b, a);
+            p = pack_r11g11b10(r, g, b);
+        } else {
+            p = ((const uint32_t*)src_v)[(size_t)sy * sw + sx];
+        }
+        tile[i] = p;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & (DOWN_TX - 1), ty = threadIdx.x / DOWN_TX;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= dw || y >= dh) return;
+    dst[(size_t)y * dst_pitch + x] = down13(tile, DOWN_SW, 2 * tx + 2, 2 * ty + 2);
+}
+
+// k_bloom_down_tail: the three small down-sample passes (mip 2 -> 3 -> 4 -> 5) in one launch. A block owns a 4x4 tile of
+// mip 5 and with it the 8x8 tile of mip 4 and the 16x16 tile of mip 3 above it. It stages the 60x60 texels of mip 2
+// that those depend on, computes the 28x28 region of mip 3 and the 12x12 region of mip 4 it needs (their borders are
+// computed again by the neighbouring blocks: same inputs, same operations, same bits), stores the tiles it owns and
+// its mip 5 texels. Three launches of a few microseconds each, mostly launch latency, become one.
+#define TAIL_T5 4
+#define TAIL_R4 (2 * TAIL_T5 + 4)
+#define TAIL_R3 (2 * TAIL_R4 + 4)
+#define TAIL_R2 (2 * TAIL_R3 + 4)
+struct BloomLevels { uint32_t* mip[6]; int w[6], h[6]; uint32_t *fin3, *fin4; };  // pointers, sizes (= row pitches) of the six mips; see k_bloom_up_tail
+__global__ void __launch_bounds__(256) k_bloom_down_tail(BloomLevels L) {
+    __shared__ uint32_t l2[TAIL_R2 * TAIL_R2], l3[TAIL_R3 * TAIL_R3], l4[TAIL_R4 * TAIL_R4];
+    const int o5x = blockIdx.x * TAIL_T5, o5y = blockIdx.y * TAIL_T5;
+    const int o4x = 2 * o5x - 2, o4y = 2 * o5y - 2, o3x = 2 * o4x - 2, o3y = 2 * o4y - 2, o2x = 2 * o3x - 2, o2y = 2 * o3y - 2;
+    for (int i = threadIdx.x; i < TAIL_R2 * TAIL_R2; i += 256) {
+        const int ly = i / TAIL_R2, lx = i - ly * TAIL_R2;
+        l2[i] = L.mip[2][(size_t)clampi(o2y + ly, 0, L.h[2] - 1) * L.w[2] + clampi(o2x + lx, 0, L.w[2] - 1)];
+    }
+    __syncthreads();
+    // mip 3 region: texel c = o3 + l reads mip 2 at clamp(2c + d), which sits at LDS index clamp(2c + d) - o2
+    for (int i = threadIdx.x; i < TAIL_R3 * TAIL_R3; i += 256) {
+        const int ly = i / TAIL_R3, lx = i - ly * TAIL_R3, cx = o3x + lx, cy = o3y + ly;
+        uint32_t v = 0u;
+        if (cx >= 0 && cy >= 0 && cx < L.w[3] && cy < L.h[3]) {
+            const int dxs[13] = {+1, +1, -1, -1, -2, 0, +2, +2, +2, 0, -2, -2, 0};
+            const int dys[13] = {+1, -1, +1, -1, -2, -2, -2, 0, +2, +2, +2, 0, 0};
+            const float ws[13] = {0.125f, 0.125f, 0.125f, 0.125f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.125f};
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 13; t++) {
+                const int sx = clampi(2 * cx + dxs[t], 0, L.w[2] - 1) - o2x, sy = clampi(2 * cy + dys[t], 0, L.h[2] - 1) - o2y;
+                float r, g, b;
+                unpack_r11g11b10(l2[sy * TAIL_R2 + sx], r, g, b);
+                a0 = fmaf(ws[t], r, a0); a1 = fmaf(ws[t], g, a1); a2 = fmaf(ws[t], b, a2);
+            }
+            v = pack_r11g11b10(a0, a1, a2);
+            // the tile this block owns: mip 3 texels [4 o5, 4 o5 + 16)
+            if (cx >= 4 * o5x && cx < 4 * o5x + 4 * TAIL_T5 && cy >= 4 * o5y && cy < 4 * o5y + 4 * TAIL_T5) L.mip[3][(size_t)cy * L.w[3] + cx] = v;
+        }
+        l3[i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < TAIL_R4 * TAIL_R4) {
+        const int i = threadIdx.x, ly = i / TAIL_R4, lx = i - ly * TAIL_R4, cx = o4x + lx, cy = o4y + ly;
+        uint32_t v = 0u;
+        if (cx >= 0 && cy >= 0 && cx < L.w[4] && cy < L.h[4]) {
+            const int dxs[13] = {+1, +1, -1, -1, -2, 0, +2, +2, +2, 0, -2, -2, 0};
+            const int dys[13] = {+1, -1, +1, -1, -2, -2, -2, 0, +2, +2, +2, 0, 0};
+            const float ws[13] = {0.125f, 0.125f, 0.125f, 0.125f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.125f};
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 13; t++) {
+                const int sx = clampi(2 * cx + dxs[t], 0, L.w[3] - 1) - o3x, sy = clampi(2 * cy + dys[t], 0, L.h[3] - 1) - o3y;
+                float r, g, b;
+                unpack_r11g11b10(l3[sy * TAIL_R3 + sx], r, g, b);
+                a0 = fmaf(ws[t], r, a0); a1 = fmaf(ws[t], g, a1); a2 = fmaf(ws[t], b, a2);
+            }
+            v = pack_r11g11b10(a0, a1, a2);
+            if (cx >= 2 * o5x && cx < 2 * o5x + 2 * TAIL_T5 && cy >= 2 * o5y && cy < 2 * o5y + 2 * TAIL_T5) L.mip[4][(size_t)cy * L.w[4] + cx] = v;
+        }
+        l4[i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < TAIL_T5 * TAIL_T5) {
+        const int cx = o5x + (int)(threadIdx.x % TAIL_T5), cy = o5y + (int)(threadIdx.x / TAIL_T5);
+        if (cx < L.w[5] && cy < L.h[5]) {
+            const int dxs[13] = {+1, +1, -1, -1, -2, 0, +2, +2, +2, 0, -2, -2, 0};
+            const int dys[13] = {+1, -1, +1, -1, -2, -2, -2, 0, +2, +2, +2, 0, 0};
+            const float ws[13] = {0.125f, 0.125f, 0.125f, 0.125f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.125f};
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 13; t++) {
+                const int sx = clampi(2 * cx + dxs[t], 0, L.w[4] - 1) - o4x, sy = clampi(2 * cy + dys[t], 0, L.h[4] - 1) - o4y;
+                float r, g, b;
+                unpack_r11g11b10(l4[sy * TAIL_R4 + sx], r, g, b);
+                a0 = fmaf(ws[t], r, a0); a1 = fmaf(ws[t], g, a1); a2 = fmaf(ws[t], b, a2);
+            }
+            L.mip[5][(size_t)cy * L.w[5] + cx] = pack_r11g11b10(a0, a1, a2);
+        }
+    }
+}
+
+// 3x3 tent of bloomUpsample.comp around source texel (ux, uy) of a packed LDS region with origin (ox, oy), added onto
+// the destination value `d` (read-modify-write of the shader), fma chain in tap order; source coordinates clamp to the
+// source image.
+RDR_DEV uint32_t tent_lds(const uint32_t* reg, int pitch, int ox, int oy, int sw, int sh, int ux, int uy, uint32_t d) {
+    const int dxs[9] = {-1, 0, +1, -1, 0, +1, -1, 0, +1};
+    const int dys[9] = {-1, -1, -1, 0, 0, 0, +1, +1, +1};
+    const float ws[9] = {0.0625f, 0.125f, 0.0625f, 0.125f, 0.25f, 0.125f, 0.0625f, 0.125f, 0.0625f};
+    float a0, a1, a2;
+    unpack_r11g11b10(d, a0, a1, a2);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int sx = clampi(ux + dxs[k], 0, sw - 1) - ox, sy = clampi(uy + dys[k], 0, sh - 1) - oy;
+        float r, g, b;
+        unpack_r11g11b10(reg[sy * pitch + sx], r, g, b);
+        a0 = fmaf(ws[k], r, a0); a1 = fmaf(ws[k], g, a1); a2 = fmaf(ws[k], b, a2);
+    }
+    return pack_r11g11b10(a0, a1, a2);
+}
+
+// k_bloom_up_tail: the three small up-sample passes (mip 5 -> 4 -> 3 -> 2) in one launch. A block owns a 32x32 tile of
+// mip 2 and the 16x16 / 8x8 tiles of mips 3 / 4 under it. It stages the 8x8 texels of mip 5, the 12x12 of mip 4 and
+// the 18x18 of mip 3 its tile depends on, accumulates level by level in LDS (mip 4 += tent(mip 5), then mip 3 +=
+// tent(mip 4), each truncated to the packed format as the separate passes store it), writes the tiles it owns and
+// finally its mip 2 texels. Region borders are recomputed by the neighbours with identical results. The accumulated
+// mips 3 and 4 go to arrays of their own (fin3, fin4): other blocks are still staging the down-sampled values of those
+// texels from mip[3] / mip[4] while this one finishes. Mip 2 is updated in place: only its owner touches a texel.
+#define UPT_T2 32
+#define UPT_R3 (UPT_T2 / 2 + 2)
+#define UPT_R4 12
+#define UPT_R5 8
+__global__ void __launch_bounds__(256) k_bloom_up_tail(BloomLevels L) {
+    __shared__ uint32_t l3[UPT_R3 * UPT_R3], l4[UPT_R4 * UPT_R4], l5[UPT_R5 * UPT_R5];
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int o2x = UPT_T2 * bx, o2y = UPT_T2 * by, o3x = 16 * bx - 1, o3y = 16 * by - 1, o4x = 8 * bx - 2, o4y = 8 * by - 2, o5x = 4 * bx - 2, o5y = 4 * by - 2;
+    if (threadIdx.x < UPT_R5 * UPT_R5) {
+        const int ly = threadIdx.x / UPT_R5, lx = threadIdx.x % UPT_R5;
+        l5[threadIdx.x] = L.mip[5][(size_t)clampi(o5y + ly, 0, L.h[5] - 1) * L.w[5] + clampi(o5x + lx, 0, L.w[5] - 1)];
+    }
+    if (threadIdx.x < UPT_R4 * UPT_R4) {
+        const int ly = threadIdx.x / UPT_R4, lx = threadIdx.x % UPT_R4;
+        l4[threadIdx.x] = L.mip[4][(size_t)clampi(o4y + ly, 0, L.h[4] - 1) * L.w[4] + clampi(o4x + lx, 0, L.w[4] - 1)];
+    }
+    for (int i = threadIdx.x; i < UPT_R3 * UPT_R3; i += 256) {
+        const int ly = i / UPT_R3, lx = i - ly * UPT_R3;
+        l3[i] = L.mip[3][(size_t)clampi(o3y + ly, 0, L.h[3] - 1) * L.w[3] + clampi(o3x + lx, 0, L.w[3] - 1)];
+    }
+    __syncthreads();
+    // mip 4 += tent(mip 5)
+    uint32_t v4 = 0u;
+    int c4x = 0, c4y = 0;
+    bool in4 = false;
+    if (threadIdx.x < UPT_R4 * UPT_R4) {
+        c4x = o4x + (int)(threadIdx.x % UPT_R4); c4y = o4y + (int)(threadIdx.x / UPT_R4);
+        in4 = c4x >= 0 && c4y >= 0 && c4x < L.w[4] && c4y < L.h[4];
+        if (in4) v4 = tent_lds(l5, UPT_R5, o5x, o5y, L.w[5], L.h[5], c4x >> 1, c4y >> 1, l4[threadIdx.x]);
+    }
+    __syncthreads();
+    if (threadIdx.x < UPT_R4 * UPT_R4 && in4) {
+        l4[threadIdx.x] = v4;
+        if (c4x >= 8 * bx && c4x < 8 * bx + 8 && c4y >= 8 * by && c4y < 8 * by + 8) L.fin4[(size_t)c4y * L.w[4] + c4x] = v4;
+    }
+    __syncthreads();
+    // mip 3 += tent(mip 4)
+    uint32_t v3[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = (int)threadIdx.x + 256 * k;
+        if (i < UPT_R3 * UPT_R3) {
+            const int cx = o3x + i % UPT_R3, cy = o3y + i / UPT_R3;
+            if (cx >= 0 && cy >= 0 && cx < L.w[3] && cy < L.h[3]) v3[k] = tent_lds(l4, UPT_R4, o4x, o4y, L.w[4], L.h[4], cx >> 1, cy >> 1, l3[i]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = (int)threadIdx.x + 256 * k;
+        if (i < UPT_R3 * UPT_R3) {
+            const int cx = o3x + i % UPT_R3, cy = o3y + i / UPT_R3;
+            if (cx >= 0 && cy >= 0 && cx < L.w[3] && cy < L.h[3]) {
+                l3[i] = v3[k];
+                if (cx >= 16 * bx && cx < 16 * bx + 16 && cy >= 16 * by && cy < 16 * by + 16) L.fin3[(size_t)cy * L.w[3] + cx] = v3[k];
+            }
+        }
+    }
+    __syncthreads();
+    // mip 2 += tent(mip 3): four texels per thread
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = (int)threadIdx.x + 256 * k, x = o2x + (i & (UPT_T2 - 1)), y = o2y + (i / UPT_T2);
+        if (x < L.w[2] && y < L.h[2]) {
+            uint32_t* p = L.mip[2] + (size_t)y * L.w[2] + x;
+            *p = tent_lds(l3, UPT_R3, o3x, o3y, L.w[3], L.h[3], x >> 1, y >> 1, *p);
+        }
+    }
+}
+
 // tonemap.comp:26-28; the two divisions feed a continuous curve, the hardware reciprocal is enough
 RDR_DEV float tone(float x) {
     const float shoulderStr = 0.22f, linStr = 0.30f, linAngle = 0.10f, toeStr = 0.20f, toeNum = 0.01f, toeDenom = 0.30f;
@@ -206,6 +436,38 @@ void launch_bloom_up(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_
     if (dw <= 0 || dh <= 0) return;
     const int qw = (dw + 1) / 2, qh = (dh + 1) / 2;
     hipLaunchKernelGGL(k_bloom_up, dim3((qw + 63) / 64, (qh + 3) / 4), dim3(256), 0, s, src, sw, sh, dst, dw, dh, dst_pitch);
+}
+// Everything of the bloom chain that precedes the tonemap kernel: five down-samples, then the up-samples down to
+// mip 1 (the last one, into mip 0, is part of the tonemap kernel). mip[k] / w[k] / h[k]: the six levels, level k of
+// size max(1, W >> k) x max(1, H >> k), rows packed. Images with at least 128 pixels a side take the staged kernels
+// (LDS tiles, the small levels fused); smaller ones, where a level can vanish, the plain per-level passes. Returns true
+// when the staged kernels ran: the accumulated mips 3 and 4 are then in fin3 / fin4 (w[3] x h[3] and w[4] x h[4]
+// texels) and mip[3] / mip[4] keep the down-sampled values; otherwise they were accumulated in place.
+bool launch_bloom_chain(hipStream_t s, const void* hdr, uint32_t* const mip[6], const int w[6], const int h[6], int W, int H, uint32_t* fin3,
+                        uint32_t* fin4) {
+    if (W >= 128 && H >= 128) {
+        BloomLevels L;
+        for (int k = 0; k < 6; k++) { L.mip[k] = mip[k]; L.w[k] = w[k]; L.h[k] = h[k]; }
+        L.fin3 = fin3; L.fin4 = fin4;
+        hipLaunchKernelGGL(k_bloom_down_lds<true>, dim3((w[1] + DOWN_TX - 1) / DOWN_TX, (h[1] + DOWN_TY - 1) / DOWN_TY), dim3(256), 0, s, hdr, w[0], h[0],
+                           mip[1], w[1], h[1], w[1]);
+        hipLaunchKernelGGL(k_bloom_down_lds<false>, dim3((w[2] + DOWN_TX - 1) / DOWN_TX, (h[2] + DOWN_TY - 1) / DOWN_TY), dim3(256), 0, s, (const void*)mip[1],
+                           w[1], h[1], mip[2], w[2], h[2], w[2]);
+        // sizes round down from level to level, so mip 3 can reach past 4x the extent of mip 5: the grid covers all three
+        const int gx = max(max((w[5] + TAIL_T5 - 1) / TAIL_T5, (w[4] + 2 * TAIL_T5 - 1) / (2 * TAIL_T5)), (w[3] + 4 * TAIL_T5 - 1) / (4 * TAIL_T5));
+        const int gy = max(max((h[5] + TAIL_T5 - 1) / TAIL_T5, (h[4] + 2 * TAIL_T5 - 1) / (2 * TAIL_T5)), (h[3] + 4 * TAIL_T5 - 1) / (4 * TAIL_T5));
+        hipLaunchKernelGGL(k_bloom_down_tail, dim3(gx, gy), dim3(256), 0, s, L);
+        hipLaunchKernelGGL(k_bloom_up_tail, dim3((w[2] + UPT_T2 - 1) / UPT_T2, (h[2] + UPT_T2 - 1) / UPT_T2), dim3(256), 0, s, L);
+        launch_bloom_up(s, mip[2], w[2], h[2], mip[1], w[1], h[1], w[1]);
+        return true;
+    }
+    for (int i = 0; i < 5; i++)
+        launch_bloom_down(s, i == 0 ? hdr : (const void*)mip[i], i == 0, w[i], h[i], mip[i + 1], W >> (i + 1), H >> (i + 1), w[i + 1]);
+    for (int i = 0; i < 4; i++) {
+        const int dl = 4 - i, sl = 5 - i;
+        launch_bloom_up(s, mip[sl], w[sl], h[sl], mip[dl], W >> dl, H >> dl, w[dl]);
+    }
+    return false;
 }
 void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* mip1, int sw, int sh, uint32_t* bloom0, uint32_t* out, float* loglum,
                     int W, int H, float scale, float inv_gamma, float white, float log2_6) {

@@ -164,7 +164,8 @@ struct rdr_ctx {
 
     // frame targets
     DevBuf d_depth, d_vis, d_samples, d_hdr, d_bloom, d_out, d_loglum, d_lum, d_dir_shadow, d_point_shadow, d_point_static;
-    uint32_t bloom_offset[6], bloom_w[6], bloom_h[6];
+    uint32_t bloom_offset[6], bloom_w[6], bloom_h[6], bloom_fin_offset[2];
+    bool bloom_fin_separate = false;  // the last chain left the accumulated mips 3 and 4 at bloom_fin_offset
     bool have_frame = false, have_post = false;
 
     // raster scratch
@@ -846,6 +847,9 @@ int ensure_post_targets(rdr_ctx* c) {
         c->bloom_offset[l] = (uint32_t)off;
         off += (size_t)c->bloom_w[l] * c->bloom_h[l];
     }
+    // the accumulated mips 3 and 4 of the fused up-sample kernel (launch_bloom_chain)
+    c->bloom_fin_offset[0] = (uint32_t)off; off += (size_t)c->bloom_w[3] * c->bloom_h[3];
+    c->bloom_fin_offset[1] = (uint32_t)off; off += (size_t)c->bloom_w[4] * c->bloom_h[4];
     HIP_TRY(c->d_bloom.ensure(off * 4));
     HIP_TRY(c->d_out.ensure(n * 4));
     HIP_TRY(c->d_loglum.ensure(n * 4));
@@ -859,14 +863,10 @@ void enqueue_post(rdr_ctx* c, hipStream_t st, float exposure, uint32_t* direct_o
     uint32_t* bloom = c->d_bloom.as<uint32_t>();
     (void)hipEventRecord(c->ev[2], st);
     // mip 0 is the colour image itself until the tonemap kernel stores its final value
-    for (uint32_t i = 0; i < 5; i++)
-        launch_bloom_down(st, i == 0 ? c->d_hdr.p : (const void*)(bloom + c->bloom_offset[i]), i == 0, (int)c->bloom_w[i], (int)c->bloom_h[i],
-                          bloom + c->bloom_offset[i + 1], (int)(c->W >> (i + 1)), (int)(c->H >> (i + 1)), (int)c->bloom_w[i + 1]);
-    for (uint32_t i = 0; i < 4; i++) {
-        const uint32_t dl = 4 - i, sl = 5 - i;
-        launch_bloom_up(st, bloom + c->bloom_offset[sl], (int)c->bloom_w[sl], (int)c->bloom_h[sl], bloom + c->bloom_offset[dl],
-                        (int)(c->W >> dl), (int)(c->H >> dl), (int)c->bloom_w[dl]);
-    }
+    uint32_t* mip[6];
+    int mw[6], mh[6];
+    for (int k = 0; k < 6; k++) { mip[k] = bloom + c->bloom_offset[k]; mw[k] = (int)c->bloom_w[k]; mh[k] = (int)c->bloom_h[k]; }
+    c->bloom_fin_separate = launch_bloom_chain(st, c->d_hdr.p, mip, mw, mh, (int)c->W, (int)c->H, bloom + c->bloom_fin_offset[0], bloom + c->bloom_fin_offset[1]);
     (void)hipEventRecord(c->ev[3], st);
     launch_tonemap(st, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, direct_out ? direct_out : c->d_out.as<uint32_t>(),
                    c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
@@ -1740,7 +1740,8 @@ static void unpack_rgb(const std::vector<uint32_t>& src, float* out) {
 int rdr_read_bloom(rdr_ctx* c, uint32_t level, float* out) {
     if (!c || !out || !c->have_post || level >= 6) return fail(c, RDR_ERR_INVALID, "read_bloom");
     std::vector<uint32_t> tmp((size_t)c->bloom_w[level] * c->bloom_h[level]);
-    RDR_TRY(read_back(c, tmp.data(), c->d_bloom.as<uint32_t>() + c->bloom_offset[level], tmp.size() * 4));
+    const uint32_t at = (c->bloom_fin_separate && (level == 3 || level == 4)) ? c->bloom_fin_offset[level - 3] : c->bloom_offset[level];
+    RDR_TRY(read_back(c, tmp.data(), c->d_bloom.as<uint32_t>() + at, tmp.size() * 4));
     unpack_rgb(tmp, out);
     return RDR_OK;
 }
@@ -1818,15 +1819,13 @@ int rdr_post_process_noalloc(rdr_ctx* c, const void* hdr_rgba16f, uint32_t width
         off[l] = (uint32_t)words;
         words += (size_t)bw[l] * bh[l];
     }
-    if (words > NOALLOC_BLOOM_WORDS) return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: bloom chain larger than the scratch array");
+    if (words + (size_t)bw[3] * bh[3] + (size_t)bw[4] * bh[4] > NOALLOC_BLOOM_WORDS)
+        return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: bloom chain larger than the scratch array");
     // the same launches, in the same order, as enqueue_post
-    for (uint32_t i = 0; i < 5; i++)
-        launch_bloom_down(st, i == 0 ? hdr_rgba16f : (const void*)(bloom + off[i]), i == 0, (int)bw[i], (int)bh[i], bloom + off[i + 1],
-                          (int)(width >> (i + 1)), (int)(height >> (i + 1)), (int)bw[i + 1]);
-    for (uint32_t i = 0; i < 4; i++) {
-        const uint32_t dl = 4 - i, sl = 5 - i;
-        launch_bloom_up(st, bloom + off[sl], (int)bw[sl], (int)bh[sl], bloom + off[dl], (int)(width >> dl), (int)(height >> dl), (int)bw[dl]);
-    }
+    uint32_t* mip[6];
+    int mw[6], mh[6];
+    for (int k = 0; k < 6; k++) { mip[k] = bloom + off[k]; mw[k] = (int)bw[k]; mh[k] = (int)bh[k]; }
+    launch_bloom_chain(st, hdr_rgba16f, mip, mw, mh, (int)width, (int)height, bloom + words, bloom + words + (size_t)bw[3] * bh[3]);
     launch_tonemap(st, hdr_rgba16f, bloom + off[1], (int)bw[1], (int)bh[1], bloom, (uint32_t*)out_rgba8, loglum, (int)width, (int)height,
                    powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
     launch_average_luminance(st, loglum, (int)width, (int)height, lum, out_avg);
