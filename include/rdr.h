@@ -332,10 +332,17 @@ int rdr_read_point_shadow(rdr_ctx* ctx, uint32_t slot, uint32_t face, float* out
 /* resolved HDR colour (RGBA, float32 values that are exactly representable
  * in the RGBA16F colour attachment), W*H*4 floats. */
 int rdr_read_hdr(rdr_ctx* ctx, float* out);
+/* Two images the reference's tonemap pass writes are read by nothing later in the frame: the accumulated bloom mip 0
+ * (Renderer/shaders/tonemap.comp:37-41 keeps it only as the bloom input of the same invocation) and, outside the
+ * 256 x 256 centre crop that the average-luminance pass reads (VulkanRenderer.cpp:1165), the log-luminance image
+ * (tonemap.comp:52). By default the HIP library does not store them (a third of the pass's memory traffic);
+ * enable != 0 makes every later frame store both so that rdr_read_bloom(ctx, 0, ..) and rdr_read_log_luminance
+ * work. The frame and its average luminance are the same either way. */
+int rdr_keep_intermediates(rdr_ctx* ctx, uint32_t enable);
 /* bloom mip `level` (0..5) decoded from B10G11R11 to RGB float32;
- * out holds (W>>level)*(H>>level)*3 floats. */
+ * out holds (W>>level)*(H>>level)*3 floats. Level 0 needs rdr_keep_intermediates. */
 int rdr_read_bloom(rdr_ctx* ctx, uint32_t level, float* out);
-/* per-pixel log-luminance image written by the tonemap pass, W*H floats. */
+/* per-pixel log-luminance image written by the tonemap pass, W*H floats. Needs rdr_keep_intermediates. */
 int rdr_read_log_luminance(rdr_ctx* ctx, float* out);
 /* irradiance cube (level must be 0) or prefiltered cube level, face-major,
  * decoded to RGB float32: 6*res*res*3 floats with res = base>>level. */

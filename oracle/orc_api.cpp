@@ -721,6 +721,7 @@ int orc_read_point_shadow(rdr_ctx* c, uint32_t slot, uint32_t face, float* out) 
     return RDR_OK;
 }
 int orc_read_hdr(rdr_ctx* c, float* out) { if (!c || !out || c->hdr.empty()) return RDR_ERR_INVALID; std::memcpy(out, c->hdr.data(), c->hdr.size() * 4); return RDR_OK; }
+int orc_keep_intermediates(rdr_ctx* c, uint32_t) { return c ? RDR_OK : RDR_ERR_INVALID; }  // every image is always kept here
 int orc_read_bloom(rdr_ctx* c, uint32_t level, float* out) {
     if (!c || !out || level >= c->bloom.size()) return RDR_ERR_INVALID;
     for (size_t i = 0; i < c->bloom[level].size(); i++) unpack_r11g11b10(c->bloom[level][i], out[i * 3], out[i * 3 + 1], out[i * 3 + 2]);

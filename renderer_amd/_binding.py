@@ -120,6 +120,7 @@ SIGNATURES = {
     "read_directional_shadow": (C.c_int, [_VP, C.c_uint32, _FP]),
     "read_point_shadow": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _FP]),
     "read_hdr": (C.c_int, [_VP, _FP]),
+    "keep_intermediates": (C.c_int, [_VP, C.c_uint32]),
     "read_bloom": (C.c_int, [_VP, C.c_uint32, _FP]),
     "read_log_luminance": (C.c_int, [_VP, _FP]),
     "read_env_cube": (C.c_int, [_VP, C.c_int, C.c_uint32, _FP]),

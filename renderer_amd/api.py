@@ -72,7 +72,9 @@ def quat_look_at(direction, up):
 class Renderer:
     """One renderer context (one GPU). Method names follow VulkanRenderer."""
 
-    def __init__(self, capi, width, height, settings=None, device=0):
+    def __init__(self, capi, width, height, settings=None, device=0, keep_intermediates=False):
+        """keep_intermediates: also store the two images nothing later in the frame reads (accumulated bloom mip 0, the
+        whole log-luminance image), which `read_bloom(0)` and `read_log_luminance` need."""
         self.api = capi
         self.width, self.height = int(width), int(height)
         self.settings = settings if settings is not None else default_settings()
@@ -82,6 +84,8 @@ class Renderer:
             self._ctx = B._VP()
             raise RendererError(f"{capi.prefix}create failed with status {rc}")
         self._keep = []
+        if keep_intermediates:
+            self.keep_intermediates(True)
 
     # -- plumbing ---------------------------------------------------------
     def close(self):
@@ -273,6 +277,9 @@ class Renderer:
         a = np.empty((self.height, self.width, 4), np.float32)
         self._check(self.api.read_hdr(self._ctx, B.fptr(a)), "read_hdr")
         return a
+
+    def keep_intermediates(self, enable=True):
+        self._check(self.api.keep_intermediates(self._ctx, 1 if enable else 0), "keep_intermediates")
 
     def read_bloom(self, level):
         w, h = max(1, self.width >> level), max(1, self.height >> level)

@@ -20,7 +20,7 @@ bool launch_bloom_chain(hipStream_t s, const void* hdr, uint32_t* const mip[6], 
                         uint32_t* fin4);
 // last up-sample (mip 1 -> mip 0) fused with the tonemap; sw/sh = 0 when the image has no mip 1
 void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* mip1, int sw, int sh, uint32_t* bloom0, uint32_t* out, float* loglum,
-                    int W, int H, float scale, float inv_gamma, float white, float log2_6);
+                    int W, int H, float scale, float inv_gamma, float white, float log2_6, bool keep);
 void launch_average_luminance(hipStream_t s, const float* loglum, int W, int H, float* l16, float* l1);
 
 // kernels_sort.hip

@@ -98,26 +98,62 @@ __global__ void __launch_bounds__(256) k_bloom_up(const uint32_t* __restrict__ s
 
 // ---- the same passes with their source tiles staged in LDS -------------------------------------------------------
 //
-// k_bloom_down_lds: a block produces DOWN_TX x DOWN_TY destination texels and first copies the (2 DOWN_TX + 4) x
-// (2 DOWN_TY + 4) source texels its 13-tap footprints cover into LDS, packed as mip texels (for the colour image: read
-// once, truncated to B10G11R11 once, instead of once per tap). Edge clamping happens while staging, so the taps index
-// LDS without tests. Values and the order of the fma chain are those of k_bloom_down: the results are identical.
+// k_bloom_down_lds: a block produces DOWN_TX x DOWN_TY destination texels (two per thread) and first copies the
+// (2 DOWN_TX + 4) x (2 DOWN_TY + 4) source texels its 13-tap footprints cover into LDS. A staged texel is three
+// binary16 values (red and green in one dword, blue in the low half of a second): B10G11R11 is binary16 without the sign
+// and the low mantissa bits, so the truncation the storage format applies is a mask on the half bits of the colour image
+// (done once per texel instead of once per tap), a packed mip texel expands with three shifts, and a tap is one 8-byte
+// LDS read plus three mixed-precision fmas that convert the half operand on the fly. Even and odd source columns are
+// kept in separate halves of a row, so the lanes of a wave (destination x = lane) read consecutive LDS words. Edge
+// clamping happens while staging. Values and the order of the fma chain are those of k_bloom_down: identical results.
 #define DOWN_TX 32
-#define DOWN_TY 8
+#define DOWN_TY 16
 #define DOWN_SW (2 * DOWN_TX + 4)
 #define DOWN_SH (2 * DOWN_TY + 4)
+#define DOWN_HW (DOWN_SW / 2)  // texels per column parity in a row
 
-// 13-tap kernel at LDS position (cx, cy) of a packed tile with row pitch `pitch`
-RDR_DEV uint32_t down13(const uint32_t* tile, int pitch, int cx, int cy) {
+typedef _Float16 rdr_f16x2 __attribute__((ext_vector_type(2)));
+RDR_DEV rdr_f16x2 as_f16x2(uint32_t u) { rdr_f16x2 h; __builtin_memcpy(&h, &u, 4); return h; }
+
+// colour-image texel (four binary16) -> staged texel: what unpack(pack_r11g11b10()) of it would give, as half bits
+RDR_DEV uint2 stage_from_hdr(uint2 t) {
+    // any exponent field all ones (inf / NaN): the exact, slower route
+    const uint32_t e0 = t.x & 0x7C007C00u, e1 = t.y & 0x7C00u;
+    if (__builtin_expect((((e0 + 0x04000400u) & 0x80008000u) | ((e1 + 0x0400u) & 0x8000u)) != 0u, 0)) {
+        const uint32_t r = ufloat_from_half_bits<6>(t.x & 0xFFFFu) << 4, g = ufloat_from_half_bits<6>(t.x >> 16) << 4;
+        const uint32_t b = ufloat_from_half_bits<5>(t.y & 0xFFFFu) << 5;
+        return make_uint2(r | (g << 16), b);
+    }
+    // finite: negative -> 0 (as 16-bit integers the negative halves are < 0), low mantissa bits dropped
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2 v0, v1;
+    __builtin_memcpy(&v0, &t.x, 4); __builtin_memcpy(&v1, &t.y, 4);
+    const s16x2 zero = {0, 0};
+    v0 = __builtin_elementwise_max(v0, zero); v1 = __builtin_elementwise_max(v1, zero);
+    uint32_t rg, b;
+    __builtin_memcpy(&rg, &v0, 4); __builtin_memcpy(&b, &v1, 4);
+    return make_uint2(rg & 0xFFF0FFF0u, b & 0x0000FFE0u);
+}
+RDR_DEV uint2 stage_from_mip(uint32_t p) {
+    return make_uint2(((p & 0x7FFu) << 4) | ((p << 9) & 0x7FF00000u), (p >> 22) << 5);
+}
+// LDS word index of source column c (0 .. DOWN_SW-1) in row r
+RDR_DEV int down_slot(int r, int c) { return r * DOWN_SW + (c & 1) * DOWN_HW + (c >> 1); }
+
+// 13-tap kernel (bloomDownsample.comp:14-33, taps in shader order) for destination texel (tx, ty) of the tile
+RDR_DEV uint32_t down13_staged(const uint2* tile, int tx, int ty) {
     const int dxs[13] = {+1, +1, -1, -1, -2, 0, +2, +2, +2, 0, -2, -2, 0};
     const int dys[13] = {+1, -1, +1, -1, -2, -2, -2, 0, +2, +2, +2, 0, 0};
     const float ws[13] = {0.125f, 0.125f, 0.125f, 0.125f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.03125f, 0.0625f, 0.125f};
+    const uint2* base = tile + (2 * ty + 2) * DOWN_SW + tx + 1;  // column 2 tx + 2: even, index tx + 1 of its half row
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
 #pragma unroll
     for (int t = 0; t < 13; t++) {
-        float r, g, b;
-        unpack_r11g11b10(tile[(cy + dys[t]) * pitch + cx + dxs[t]], r, g, b);
-        acc0 = fmaf(ws[t], r, acc0); acc1 = fmaf(ws[t], g, acc1); acc2 = fmaf(ws[t], b, acc2);
+        // column 2 tx + 2 + dx: parity of dx, index tx + 1 + floor(dx / 2)
+        const int off = dys[t] * DOWN_SW + (dxs[t] & 1) * DOWN_HW + (dxs[t] >> 1);
+        const uint2 v = base[off];
+        const rdr_f16x2 rg = as_f16x2(v.x), bb = as_f16x2(v.y);
+        acc0 = fmaf(ws[t], (float)rg.x, acc0); acc1 = fmaf(ws[t], (float)rg.y, acc1); acc2 = fmaf(ws[t], (float)bb.x, acc2);
     }
     return pack_r11g11b10(acc0, acc1, acc2);
 }
@@ -125,27 +161,43 @@ RDR_DEV uint32_t down13(const uint32_t* tile, int pitch, int cx, int cy) {
 template <bool FROM_HDR>
 __global__ void __launch_bounds__(256) k_bloom_down_lds(const void* __restrict__ src_v, int sw, int sh, uint32_t* __restrict__ dst,
                                                         int dw, int dh, int dst_pitch) {
-    __shared__ uint32_t tile[DOWN_SH * DOWN_SW];
+    __shared__ uint2 tile[DOWN_SH * DOWN_SW];
     const int x0 = blockIdx.x * DOWN_TX, y0 = blockIdx.y * DOWN_TY;
     const int sx0 = 2 * x0 - 2, sy0 = 2 * y0 - 2;
-    for (int i = threadIdx.x; i < DOWN_SH * DOWN_SW; i += 256) {
-        const int ly = i / DOWN_SW, lx = i - ly * DOWN_SW;
-        const int sx = clampi(sx0 + lx, 0, sw - 1), sy = clampi(sy0 + ly, 0, sh - 1);
-        uint32_t p;
-        if (FROM_HDR) {
-            float r, g, b, a;
-            unpack_half4(((const uint2*)src_v)[(size_t)sy * sw + sx], r, g, b, a);
-            p = pack_r11g11b10(r, g, b);
-        } else {
-            p = ((const uint32_t*)src_v)[(size_t)sy * sw + sx];
+    // the whole source tile inside the image and rows that keep pairs of texels aligned: two texels per load, no clamps
+    const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + DOWN_SW <= sw && sy0 + DOWN_SH <= sh && (sw & 1) == 0;
+    if (interior) {
+        for (int i = threadIdx.x; i < DOWN_SH * DOWN_HW; i += 256) {
+            const int ly = i / DOWN_HW, lp = i - ly * DOWN_HW;  // pair lp = columns 2 lp, 2 lp + 1
+            const size_t at = (size_t)(sy0 + ly) * sw + sx0 + 2 * lp;
+            uint2 e, o;
+            if (FROM_HDR) {
+                const uint4 v = *(const uint4*)((const uint2*)src_v + at);
+                e = stage_from_hdr(make_uint2(v.x, v.y)); o = stage_from_hdr(make_uint2(v.z, v.w));
+            } else {
+                const uint2 v = *(const uint2*)((const uint32_t*)src_v + at);
+                e = stage_from_mip(v.x); o = stage_from_mip(v.y);
+            }
+            tile[ly * DOWN_SW + lp] = e;
+            tile[ly * DOWN_SW + DOWN_HW + lp] = o;
         }
-        tile[i] = p;
+    } else {
+        for (int i = threadIdx.x; i < DOWN_SH * DOWN_SW; i += 256) {
+            const int ly = i / DOWN_SW, lx = i - ly * DOWN_SW;
+            const int sx = clampi(sx0 + lx, 0, sw - 1), sy = clampi(sy0 + ly, 0, sh - 1);
+            tile[down_slot(ly, lx)] = FROM_HDR ? stage_from_hdr(((const uint2*)src_v)[(size_t)sy * sw + sx])
+                                               : stage_from_mip(((const uint32_t*)src_v)[(size_t)sy * sw + sx]);
+        }
     }
     __syncthreads();
     const int tx = threadIdx.x & (DOWN_TX - 1), ty = threadIdx.x / DOWN_TX;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= dw || y >= dh) return;
-    dst[(size_t)y * dst_pitch + x] = down13(tile, DOWN_SW, 2 * tx + 2, 2 * ty + 2);
+    const int x = x0 + tx;
+    if (x >= dw) return;
+#pragma unroll
+    for (int k = 0; k < DOWN_TY / 8; k++) {
+        const int y = y0 + ty + 8 * k;
+        if (y < dh) dst[(size_t)y * dst_pitch + x] = down13_staged(tile, tx, ty + 8 * k);
+    }
 }
 
 // k_bloom_down_tail: the three small down-sample passes (mip 2 -> 3 -> 4 -> 5) in one launch. A block owns a 4x4 tile of
@@ -328,6 +380,7 @@ __global__ void __launch_bounds__(256) k_bloom_up_tail(BloomLevels L) {
 
 // tonemap.comp:26-28; the two divisions feed a continuous curve, the hardware reciprocal is enough
 RDR_DEV float tone(float x) {
+#pragma clang fp contract(fast)
     const float shoulderStr = 0.22f, linStr = 0.30f, linAngle = 0.10f, toeStr = 0.20f, toeNum = 0.01f, toeDenom = 0.30f;
     return ((x * (shoulderStr * x + linAngle * linStr) + toeStr * toeNum) * __builtin_amdgcn_rcpf(x * (shoulderStr * x + linStr) + toeStr * toeDenom)) - toeNum / toeDenom;
 }
@@ -336,6 +389,7 @@ RDR_DEV float tone(float x) {
 // first is <= 0 and the second sees [0, 1), so the library's range fix-ups buy nothing at 8-bit output precision.
 // `scale2` = 2^exposure * log2(e).
 RDR_DEV uint32_t tonemap_channel(float c, float bloom, float scale2, float inv_gamma, float inv_white) {
+#pragma clang fp contract(fast)
     float v = c * (1.0f - 0.04f) + bloom * 0.04f;
     v = tone(v) * inv_white;
     v = 1.0f - __builtin_amdgcn_exp2f(-v * scale2);
@@ -343,18 +397,43 @@ RDR_DEV uint32_t tonemap_channel(float c, float bloom, float scale2, float inv_g
     return (uint32_t)(int)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f);  // UNORM8, NaN -> 0
 }
 
+// the nine tent taps around (ux, uy) as staged texels (binary16 values, see stage_from_mip): the fma chain converts them
+// on the fly
+struct TentH { uint32_t rg[9], b[9]; };
+RDR_DEV void load_tent_h(const uint32_t* __restrict__ src, int sw, int sh, int ux, int uy, TentH& t) {
+    const int dxs[9] = {-1, 0, +1, -1, 0, +1, -1, 0, +1};
+    const int dys[9] = {-1, -1, -1, 0, 0, 0, +1, +1, +1};
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int sx = clampi(ux + dxs[k], 0, sw - 1), sy = clampi(uy + dys[k], 0, sh - 1);
+        const uint2 v = stage_from_mip(src[(size_t)sy * sw + sx]);
+        t.rg[k] = v.x; t.b[k] = v.y;
+    }
+}
+RDR_DEV void tent_accumulate_h(const TentH& t, float& acc0, float& acc1, float& acc2) {
+    const float ws[9] = {0.0625f, 0.125f, 0.0625f, 0.125f, 0.25f, 0.125f, 0.0625f, 0.125f, 0.0625f};
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const rdr_f16x2 rg = as_f16x2(t.rg[k]), bb = as_f16x2(t.b[k]);
+        acc0 = fmaf(ws[k], (float)rg.x, acc0); acc1 = fmaf(ws[k], (float)rg.y, acc1); acc2 = fmaf(ws[k], (float)bb.x, acc2);
+    }
+}
+
 // Last up-sample (mip 1 -> mip 0, destination read from the colour image) + tonemap.comp:34-53 for a 2x2 quad.
 // `inv_white` = 1 / tone(11.2) from the host. VEC: the image width is even, so the two pixels of a quad row are
-// one 16-byte load and 8-byte stores.
-template <bool VEC>
+// one 16-byte load and 8-byte stores. KEEP: also store the accumulated mip 0 and the whole log-luminance image (the
+// shader writes both; nothing later in the frame reads mip 0, and the average-luminance pass reads only the centre
+// crop [cx0, cx1] x [cy0, cy1] of the log-luminance, which is always stored).
+template <bool VEC, bool KEEP>
 __global__ void __launch_bounds__(256) k_tonemap(const uint2* __restrict__ hdr, const uint32_t* __restrict__ mip1, int sw, int sh,
                                                  uint32_t* __restrict__ bloom0, uint32_t* __restrict__ out, float* __restrict__ loglum,
-                                                 int W, int H, float scale2, float inv_gamma, float inv_white, float log2_6) {
+                                                 int W, int H, float scale2, float inv_gamma, float inv_white, float log2_6, int cx0, int cx1,
+                                                 int cy0, int cy1) {
     const int qx = blockIdx.x * 64 + (threadIdx.x & 63), qy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (2 * qx >= W || 2 * qy >= H) return;
-    Tent t;
+    TentH t;
     const bool have_mip1 = sw > 0 && sh > 0;
-    if (have_mip1) load_tent(mip1, sw, sh, qx, qy, t);
+    if (have_mip1) load_tent_h(mip1, sw, sh, qx, qy, t);
 #pragma unroll
     for (int oy = 0; oy < 2; oy++) {
         const int y = 2 * qy + oy;
@@ -363,30 +442,49 @@ __global__ void __launch_bounds__(256) k_tonemap(const uint2* __restrict__ hdr, 
         uint2 h[2];
         if (VEC) { const uint4 v = *(const uint4*)(hdr + i0); h[0] = make_uint2(v.x, v.y); h[1] = make_uint2(v.z, v.w); }
         else { h[0] = hdr[i0]; h[1] = (2 * qx + 1 < W) ? hdr[i0 + 1] : make_uint2(0u, 0u); }
-        uint32_t b0[2], px[2];
+        uint32_t b0[2] = {0u, 0u}, px[2];
         float ll[2];
 #pragma unroll
         for (int ox = 0; ox < 2; ox++) {
             float c[3], a, bl[3];
             unpack_half4(h[ox], c[0], c[1], c[2], a);
-            b0[ox] = pack_r11g11b10(c[0], c[1], c[2]);
+            // mip 0 = the colour truncated to the packed format (a mask on its half bits), plus the tent of mip 1
+            const uint2 m0 = stage_from_hdr(h[ox]);
+            uint32_t trg = m0.x, tb = m0.y;  // mip 0 as half bits: red | green << 16, blue
             if (have_mip1) {
-                unpack_r11g11b10(b0[ox], bl[0], bl[1], bl[2]);
-                b0[ox] = tent_accumulate(t, bl[0], bl[1], bl[2]);
+                const rdr_f16x2 rg = as_f16x2(m0.x), bb = as_f16x2(m0.y);
+                float a0 = (float)rg.x, a1 = (float)rg.y, a2 = (float)bb.x;
+                tent_accumulate_h(t, a0, a1, a2);
+                // the accumulated value as the packed format stores it. The sums are never negative, so the truncation is
+                // a round-toward-zero conversion to half and a mask; NaNs stay NaNs (quiet bit above the mask)
+                if (KEEP) b0[ox] = pack_r11g11b10(a0, a1, a2);
+                trg = half2_bits_rtz(a0, a1) & 0xFFF0FFF0u; tb = half2_bits_rtz(a2, 0.0f) & 0xFFE0u;
+            } else if (KEEP) {
+                b0[ox] = (m0.x >> 4 & 0x7FFu) | (m0.x >> 9 & 0x3FF800u) | (m0.y >> 5 << 22);
             }
-            unpack_r11g11b10(b0[ox], bl[0], bl[1], bl[2]);
+            {
+                const rdr_f16x2 rg = as_f16x2(trg), bb = as_f16x2(tb);
+                bl[0] = (float)rg.x; bl[1] = (float)rg.y; bl[2] = (float)bb.x;
+            }
             ll[ox] = __builtin_amdgcn_logf((2.0f * c[0] + 3.0f * c[1]) + c[2]) - log2_6;
             px[ox] = 0xFF000000u | tonemap_channel(c[0], bl[0], scale2, inv_gamma, inv_white) |
                      (tonemap_channel(c[1], bl[1], scale2, inv_gamma, inv_white) << 8) |
                      (tonemap_channel(c[2], bl[2], scale2, inv_gamma, inv_white) << 16);
         }
+        const bool lum = KEEP || (y >= cy0 && y <= cy1 && 2 * qx + 1 >= cx0 && 2 * qx <= cx1);
         if (VEC) {
-            *(uint2*)(bloom0 + i0) = make_uint2(b0[0], b0[1]);
+            if (KEEP) *(uint2*)(bloom0 + i0) = make_uint2(b0[0], b0[1]);
             *(uint2*)(out + i0) = make_uint2(px[0], px[1]);
-            *(float2*)(loglum + i0) = make_float2(ll[0], ll[1]);
+            if (lum) *(float2*)(loglum + i0) = make_float2(ll[0], ll[1]);
         } else {
-            bloom0[i0] = b0[0]; out[i0] = px[0]; loglum[i0] = ll[0];
-            if (2 * qx + 1 < W) { bloom0[i0 + 1] = b0[1]; out[i0 + 1] = px[1]; loglum[i0 + 1] = ll[1]; }
+            out[i0] = px[0];
+            if (KEEP) bloom0[i0] = b0[0];
+            if (lum) loglum[i0] = ll[0];
+            if (2 * qx + 1 < W) {
+                out[i0 + 1] = px[1];
+                if (KEEP) bloom0[i0 + 1] = b0[1];
+                if (lum) loglum[i0 + 1] = ll[1];
+            }
         }
     }
 }
@@ -470,14 +568,18 @@ bool launch_bloom_chain(hipStream_t s, const void* hdr, uint32_t* const mip[6], 
     return false;
 }
 void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* mip1, int sw, int sh, uint32_t* bloom0, uint32_t* out, float* loglum,
-                    int W, int H, float scale, float inv_gamma, float white, float log2_6) {
+                    int W, int H, float scale, float inv_gamma, float white, float log2_6, bool keep) {
     const int qw = (W + 1) / 2, qh = (H + 1) / 2;
     const float scale2 = scale * 1.44269504088896340736f;  // exp(-x s) = exp2(-x s log2 e)
     const dim3 grid((qw + 63) / 64, (qh + 3) / 4);
-    if ((W & 1) == 0)
-        hipLaunchKernelGGL(k_tonemap<true>, grid, dim3(256), 0, s, (const uint2*)hdr, mip1, sw, sh, bloom0, out, loglum, W, H, scale2, inv_gamma, 1.0f / white, log2_6);
-    else
-        hipLaunchKernelGGL(k_tonemap<false>, grid, dim3(256), 0, s, (const uint2*)hdr, mip1, sw, sh, bloom0, out, loglum, W, H, scale2, inv_gamma, 1.0f / white, log2_6);
+    // what launch_average_luminance reads: 256 x 256 texels from (W/2 - 128, H/2 - 128), coordinates clamped to the image
+    const int cx0 = max(W / 2 - 128, 0), cx1 = min(W / 2 + 127, W - 1), cy0 = max(H / 2 - 128, 0), cy1 = min(H / 2 + 127, H - 1);
+#define RDR_TONEMAP(VEC, KEEP)                                                                                                          \
+    hipLaunchKernelGGL((k_tonemap<VEC, KEEP>), grid, dim3(256), 0, s, (const uint2*)hdr, mip1, sw, sh, bloom0, out, loglum, W, H, scale2, \
+                       inv_gamma, 1.0f / white, log2_6, cx0, cx1, cy0, cy1)
+    if ((W & 1) == 0) { if (keep) RDR_TONEMAP(true, true); else RDR_TONEMAP(true, false); }
+    else { if (keep) RDR_TONEMAP(false, true); else RDR_TONEMAP(false, false); }
+#undef RDR_TONEMAP
 }
 void launch_average_luminance(hipStream_t s, const float* loglum, int W, int H, float* l16, float* l1) {
     hipLaunchKernelGGL(k_lum_reduce, dim3(256), dim3(64), 0, s, loglum, W, H, W / 2 - 128, H / 2 - 128, 0, l16, 16);

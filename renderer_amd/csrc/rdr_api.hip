@@ -165,6 +165,8 @@ struct rdr_ctx {
     // frame targets
     DevBuf d_depth, d_vis, d_samples, d_hdr, d_bloom, d_out, d_loglum, d_lum, d_dir_shadow, d_point_shadow, d_point_static;
     uint32_t bloom_offset[6], bloom_w[6], bloom_h[6], bloom_fin_offset[2];
+    bool keep_intermediates = false;  // rdr_keep_intermediates: the tonemap kernel also stores mip 0 and the whole log-luminance image
+    bool post_kept = false;           // ... and did so in the last post-process pass
     bool bloom_fin_separate = false;  // the last chain left the accumulated mips 3 and 4 at bloom_fin_offset
     bool have_frame = false, have_post = false;
 
@@ -602,6 +604,22 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     uint32_t* vals[2] = {c->d_vals[0].as<uint32_t>(), c->d_vals[1].as<uint32_t>()};
     const int cur = launch_radix_sort(c->stream, keys, vals, n_pairs, key_bits, c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(), counters + 2);
     launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), n_tiles);
+    if (getenv("RDR_DEBUG_TILE_LISTS")) {  // diagnostic: list length per tile, per view
+        std::vector<uint32_t> tr((size_t)n_tiles * 2);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(tr.data(), c->d_tile_start.p, tr.size() * 4, hipMemcpyDeviceToHost);
+        for (const DView& v : b.views) {
+            const uint32_t nt = v.tiles_x * v.tiles_y;
+            uint64_t sum = 0; uint32_t mx = 0, nonempty = 0, over[4] = {0, 0, 0, 0};
+            for (uint32_t t = v.tile_base; t < v.tile_base + nt; t++) {
+                const uint32_t len = tr[n_tiles + t] - tr[t];
+                sum += len; mx = std::max(mx, len); nonempty += len > 0;
+                over[0] += len > 64; over[1] += len > 256; over[2] += len > 1024; over[3] += len > 4096;
+            }
+            fprintf(stderr, "view %ux%u s%u load %u: tiles %u nonempty %u pairs %llu max %u  >64:%u >256:%u >1024:%u >4096:%u\n", v.w, v.h, v.samples,
+                    v.load, nt, nonempty, (unsigned long long)sum, mx, over[0], over[1], over[2], over[3]);
+        }
+    }
     c->stats.triangle_instances += n_inst;
     c->stats.tile_pairs += n_pairs;
     c->stats.views += (uint32_t)b.views.size();
@@ -845,10 +863,10 @@ int ensure_post_targets(rdr_ctx* c) {
     for (uint32_t l = 0; l < 6; l++) {
         c->bloom_w[l] = std::max(1u, c->W >> l); c->bloom_h[l] = std::max(1u, c->H >> l);
         c->bloom_offset[l] = (uint32_t)off;
-        off += (size_t)c->bloom_w[l] * c->bloom_h[l];
+        off += ((size_t)c->bloom_w[l] * c->bloom_h[l] + 3u) & ~(size_t)3u;  // every level starts on a 16-byte boundary
     }
     // the accumulated mips 3 and 4 of the fused up-sample kernel (launch_bloom_chain)
-    c->bloom_fin_offset[0] = (uint32_t)off; off += (size_t)c->bloom_w[3] * c->bloom_h[3];
+    c->bloom_fin_offset[0] = (uint32_t)off; off += ((size_t)c->bloom_w[3] * c->bloom_h[3] + 3u) & ~(size_t)3u;
     c->bloom_fin_offset[1] = (uint32_t)off; off += (size_t)c->bloom_w[4] * c->bloom_h[4];
     HIP_TRY(c->d_bloom.ensure(off * 4));
     HIP_TRY(c->d_out.ensure(n * 4));
@@ -869,7 +887,9 @@ void enqueue_post(rdr_ctx* c, hipStream_t st, float exposure, uint32_t* direct_o
     c->bloom_fin_separate = launch_bloom_chain(st, c->d_hdr.p, mip, mw, mh, (int)c->W, (int)c->H, bloom + c->bloom_fin_offset[0], bloom + c->bloom_fin_offset[1]);
     (void)hipEventRecord(c->ev[3], st);
     launch_tonemap(st, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, direct_out ? direct_out : c->d_out.as<uint32_t>(),
-                   c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
+                   c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f),
+                   c->keep_intermediates);
+    c->post_kept = c->keep_intermediates;
     launch_average_luminance(st, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), (float*)frame_counters(c) + RDR_COUNTER_LUM);
     (void)hipEventRecord(c->ev[4], st);
     c->have_post = true;
@@ -1737,8 +1757,15 @@ static void unpack_rgb(const std::vector<uint32_t>& src, float* out) {
         out[i * 3 + 2] = ufloat_decode(src[i] >> 22, 5);
     }
 }
+int rdr_keep_intermediates(rdr_ctx* c, uint32_t enable) {
+    if (!c) return RDR_ERR_INVALID;
+    c->keep_intermediates = enable != 0;
+    return RDR_OK;
+}
+
 int rdr_read_bloom(rdr_ctx* c, uint32_t level, float* out) {
     if (!c || !out || !c->have_post || level >= 6) return fail(c, RDR_ERR_INVALID, "read_bloom");
+    if (level == 0 && !c->post_kept) return fail(c, RDR_ERR_INVALID, "read_bloom: mip 0 is only stored after rdr_keep_intermediates(ctx, 1)");
     std::vector<uint32_t> tmp((size_t)c->bloom_w[level] * c->bloom_h[level]);
     const uint32_t at = (c->bloom_fin_separate && (level == 3 || level == 4)) ? c->bloom_fin_offset[level - 3] : c->bloom_offset[level];
     RDR_TRY(read_back(c, tmp.data(), c->d_bloom.as<uint32_t>() + at, tmp.size() * 4));
@@ -1747,6 +1774,7 @@ int rdr_read_bloom(rdr_ctx* c, uint32_t level, float* out) {
 }
 int rdr_read_log_luminance(rdr_ctx* c, float* out) {
     if (!c || !out || !c->have_post) return fail(c, RDR_ERR_INVALID, "read_log_luminance");
+    if (!c->post_kept) return fail(c, RDR_ERR_INVALID, "read_log_luminance: the whole image is only stored after rdr_keep_intermediates(ctx, 1)");
     return read_back(c, out, c->d_loglum.p, (size_t)c->W * c->H * 4);
 }
 int rdr_read_env_cube(rdr_ctx* c, int which, uint32_t level, float* out) {
@@ -1817,17 +1845,18 @@ int rdr_post_process_noalloc(rdr_ctx* c, const void* hdr_rgba16f, uint32_t width
     for (uint32_t l = 0; l < 6; l++) {
         bw[l] = std::max(1u, width >> l); bh[l] = std::max(1u, height >> l);
         off[l] = (uint32_t)words;
-        words += (size_t)bw[l] * bh[l];
+        words += ((size_t)bw[l] * bh[l] + 3u) & ~(size_t)3u;
     }
-    if (words + (size_t)bw[3] * bh[3] + (size_t)bw[4] * bh[4] > NOALLOC_BLOOM_WORDS)
+    const size_t fin4_at = words + (((size_t)bw[3] * bh[3] + 3u) & ~(size_t)3u);
+    if (fin4_at + (size_t)bw[4] * bh[4] > NOALLOC_BLOOM_WORDS)
         return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: bloom chain larger than the scratch array");
     // the same launches, in the same order, as enqueue_post
     uint32_t* mip[6];
     int mw[6], mh[6];
     for (int k = 0; k < 6; k++) { mip[k] = bloom + off[k]; mw[k] = (int)bw[k]; mh[k] = (int)bh[k]; }
-    launch_bloom_chain(st, hdr_rgba16f, mip, mw, mh, (int)width, (int)height, bloom + words, bloom + words + (size_t)bw[3] * bh[3]);
+    launch_bloom_chain(st, hdr_rgba16f, mip, mw, mh, (int)width, (int)height, bloom + words, bloom + fin4_at);
     launch_tonemap(st, hdr_rgba16f, bloom + off[1], (int)bw[1], (int)bh[1], bloom, (uint32_t*)out_rgba8, loglum, (int)width, (int)height,
-                   powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f));
+                   powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f), false);
     launch_average_luminance(st, loglum, (int)width, (int)height, lum, out_avg);
     HIP_TRY(hipGetLastError());
     return RDR_OK;

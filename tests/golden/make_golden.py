@@ -60,7 +60,7 @@ def post_case(capi, seed=7, W=80, H=48, exposure=1.5):
     rng = np.random.default_rng(seed)
     hdr = (rng.random((H, W, 4), dtype=np.float32) ** 3 * 5.0).astype(np.float32)
     hdr[rng.random((H, W)) > 0.99, :3] *= 30.0
-    r = Renderer(capi, W, H, default_settings())
+    r = Renderer(capi, W, H, default_settings(), keep_intermediates=True)
     out, avg = r.post_process(hdr, exposure)
     res = {"hdr_in": hdr, "rgba8": out, "avg_log_luminance": np.float32(avg), "bloom0": r.read_bloom(0), "bloom5": r.read_bloom(5)}
     r.close()

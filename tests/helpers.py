@@ -12,7 +12,7 @@ def psnr(a, b):
 
 def make_pair(orc_capi, hip_capi, W, H, **settings):
     s1, s2 = default_settings(**settings), default_settings(**settings)
-    return Renderer(orc_capi, W, H, s1), Renderer(hip_capi, W, H, s2)
+    return Renderer(orc_capi, W, H, s1, keep_intermediates=True), Renderer(hip_capi, W, H, s2, keep_intermediates=True)
 
 
 def small_settings(msaa=1):

@@ -99,8 +99,16 @@ def test_full_size_properties_4k(hip_capi):
     W, H = 3840, 2160
     r = Renderer(hip_capi, W, H, default_settings(msaa=4))
     scenes.sponza_like(r, tex_size=256, env_res=64, detail=0.5)
+    lean, avg_lean = r.render_frame(**FRAME)
+    lean = lean.copy()
+    with pytest.raises(Exception, match="keep_intermediates"):
+        r.read_log_luminance()
+    with pytest.raises(Exception, match="keep_intermediates"):
+        r.read_bloom(0)
+    r.keep_intermediates(True)
     a, avg_a = r.render_frame(**FRAME)
     a = a.copy()
+    assert np.array_equal(a, lean) and avg_a == avg_lean, "storing the intermediate images must not change the frame"
     depth, vis = r.read_depth(), r.read_visibility()
     assert np.array_equal((vis == 0xFFFFFFFF), (depth >= 1.0)), "a sample is covered exactly when its depth was written"
     assert depth.min() >= 0.0 and depth.max() <= 1.0
