@@ -219,6 +219,11 @@ typedef struct rdr_frame_stats {
     uint32_t blend_groups;        /* 0: the blended pass ran over all tiles at once; n > 0: its fragment list would have exceeded
                                    * the context's budget and the tiles were rendered in n groups (same result, bounded memory) */
     float host_ms;                /* host time rdr_render_frame spent building and enqueueing this frame (culling, ordering, uploads) */
+    uint32_t views_reused;        /* shadow views (cascades, point-light faces) not rendered because nothing that goes into them
+                                   * changed since they were last rendered; they are not part of `views` and the counters above.
+                                   * The reference redraws them every frame (VulkanRendererShadow.cpp:348, 424); 0 from the CPU checker */
+    uint32_t draw_lists_on_device; /* 1: culling and ordering of the primitives per view ran on the GPU (scenes with >= 2048
+                                   * primitives), 0: in the host loop that follows drawMeshes (VulkanRenderer.cpp:945-999) */
 } rdr_frame_stats;
 
 /* ---- lifetime ---------------------------------------------------------- */

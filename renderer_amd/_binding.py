@@ -82,7 +82,8 @@ class FrameStats(C.Structure):
                 ("views", C.c_uint32), ("draws_main", C.c_uint32), ("ms_geometry", C.c_float), ("ms_shade", C.c_float),
                 ("ms_bloom", C.c_float), ("ms_tonemap", C.c_float), ("ms_total", C.c_float), ("exposure", C.c_float),
                 ("avg_log_luminance", C.c_float), ("ms_shade_kernel", C.c_float), ("ms_raster_kernel", C.c_float),
-                ("chunks_culled", C.c_uint64), ("frame_index", C.c_uint64), ("blend_groups", C.c_uint32), ("host_ms", C.c_float)]
+                ("chunks_culled", C.c_uint64), ("frame_index", C.c_uint64), ("blend_groups", C.c_uint32), ("host_ms", C.c_float),
+                ("views_reused", C.c_uint32), ("draw_lists_on_device", C.c_uint32)]
 
 
 _VP = C.c_void_p

@@ -31,6 +31,13 @@ size_t sort_hist_words(uint32_t n);
 int launch_radix_sort(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, uint32_t key_bits, uint32_t* hist,
                       uint32_t* scan_scratch, uint32_t* d_dummy_total);
 
+// kernels_draws.hip
+size_t draw_list_scratch_words(uint32_t n_slots, uint32_t longest_sorted);
+void launch_draw_lists(hipStream_t s, const DDrawList* lists, uint32_t n_lists, const DDrawList* d_lists, uint32_t n_slots,
+                       const DPrimCull* prims, const float* models, const uint32_t* cand, uint32_t* scratch, uint32_t* sort_hist,
+                       uint32_t* scan_scratch, DDraw* draws, uint32_t* draw_first, uint32_t* first_tri, uint32_t* chunk_first,
+                       DDrawListInfo* info, DView* views, uint32_t* totals);
+
 // kernels_raster.hip
 void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const uint32_t* draw_first, uint32_t n_draws, uint32_t n_inst,
                   const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned,

@@ -509,15 +509,25 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
     __shared__ uint32_t lds_cover[RASTER_CHUNK];     // RASTER_EXACT64 / RASTER_COVER / RASTER_LOCAL32, see below
     __shared__ unsigned long long lds_key[S * 256];  // [sample][pixel of the tile, row-major]
     const uint32_t tile = tile_origin + blockIdx.x;
-    // view of this tile: largest v with tile_base <= tile (views are few; block-uniform loop)
+    // A tile's life is a chain of dependent loads, and what a CU gets done is set by the length of that chain: the list
+    // bounds are fetched first, the view table is searched by the lanes of the wave side by side (one round trip, not
+    // one per view), and the first triangle ids are on their way while the view's parameters arrive.
+    const uint32_t begin = tile_start[tile], end = tile_end[tile];
+    // view of this tile: the last one whose first tile is <= tile (views are laid out in order of their tiles)
     uint32_t v = first_view;
-    for (uint32_t k = first_view + 1; k < n_views; k++) if (views[k].tile_base <= tile) v = k;
+    for (uint32_t k0 = first_view + 1; k0 < n_views; k0 += 64u) {
+        const uint32_t k = k0 + (threadIdx.x & 63u);
+        const unsigned long long below = __ballot(k < n_views && views[k].tile_base <= tile);
+        if (below) v = k0 + 63u - (uint32_t)__builtin_clzll(below);
+    }
+    v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    uint32_t next_id = 0u;  // triangle id this thread stages for the coming chunk
+    if (begin + threadIdx.x < end && threadIdx.x < (uint32_t)RASTER_CHUNK) next_id = sorted_vals[begin + threadIdx.x];
     const DView vw = views[v];
     if ((S == 4) != (vw.samples == 4u)) return;  // the other instantiation handles it
-    if (vw.load == 2u) return;                    // tiles of the blended pass: binned here, rasterised with their shading
+    if (vw.load >= 2u) return;                    // 2: tiles of the blended pass, binned here, rasterised with their shading; 3: a view that was dropped
     const uint32_t local_tile = tile - vw.tile_base;
     if (local_tile >= vw.tiles_x * vw.tiles_y) return;
-    const uint32_t begin = tile_start[tile], end = tile_end[tile];
     // load == 1 with the initial depth in another buffer (a point-light face that starts from its cached static map):
     // the tile is carried over here, so no separate copy of the map is needed
     const bool carry = vw.load && vw.init != vw.depth;
@@ -569,8 +579,10 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
     for (uint32_t base = begin; base < end; base += RASTER_CHUNK) {
         const uint32_t cnt = min((uint32_t)RASTER_CHUNK, end - base);
         __syncthreads();  // the previous chunk's items are done with lds_rec (first pass: the keys are initialised)
-        if ((uint32_t)tid < cnt) lds_ids[tid] = sorted_vals[base + tid];
+        if ((uint32_t)tid < cnt) lds_ids[tid] = next_id;
         __syncthreads();
+        // the ids of the chunk after this one: in flight while this one is staged and rasterised
+        if (tid < RASTER_CHUNK && base + RASTER_CHUNK + (uint32_t)tid < end) next_id = sorted_vals[base + RASTER_CHUNK + tid];
         // 32 consecutive threads copy one 128-byte record
         for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += (uint32_t)T)
             lds_rec[dw] = ((const uint32_t*)(recs + lds_ids[dw >> 5]))[dw & 31u];

@@ -107,9 +107,15 @@ struct HostMesh {
 };
 struct HostLight { vec3 point, intensity; uint32_t flags; uint16_t slot; };
 
+// One batch of views binned, sorted and rasterised together. Its draws come either from the host (`draws`, filled by
+// append_draws) or from the draw-list kernels (`lists`, one per view that has candidates); bin_batch leaves in
+// `info[v]` where the draws and triangle instances of view v sit in the batch's tables on either path.
 struct Batch {
     std::vector<DView> views;
     std::vector<DDraw> draws;
+    std::vector<DDrawList> lists;
+    std::vector<DDrawListInfo> info;
+    uint32_t views_dropped = 0;  // views whose list came out empty and that are therefore not rendered (DDrawList::drop_empty)
 };
 
 // Scratch of rdr_post_process_noalloc: bloom mips 0..5, the log-luminance image and the 16x16 partial means of the
@@ -183,12 +189,28 @@ struct rdr_ctx {
     DevBuf d_keys[2], d_vals[2];
     DevBuf d_shade_tris;  // DShadeTri per triangle of the view being shaded
     PinBuf h_stage, h_read;
-    std::vector<DDraw> main_draws;  // opaque draws of the last frame (kept for read-backs)
+    // Draw lists built on the GPU (kernels_draws.hip) once a scene has enough primitives for the host loop over
+    // views x primitives to matter; RDR_DEVICE_DRAW_LISTS=0/1 forces either path (tests run both).
+    bool device_draws = false;       // this frame's choice
+    uint64_t cull_tables_frame = 0;  // frame the tables below were last uploaded for
+    DevBuf d_prim_cull, d_models, d_cand, d_draw_scratch;
+    PinBuf h_cull;
+    uint32_t cand_first[4] = {0, 0, 0, 0}, cand_count[4] = {0, 0, 0, 0};  // opaque, non-opaque, static, dynamic primitives in d_cand
+    uint64_t cand_tris[5] = {0, 0, 0, 0, 0};                                // triangles of those four lists and of all primitives
     uint32_t batch_instances = 0;   // triangle instances of the last raster batch
     uint64_t blend_pairs = 0, blend_box_pixels = 0;  // of the last batch: (triangle, tile) pairs / box pixels of blended-view triangles
     DevBuf d_frags, d_frag_col, d_frag_head, d_tile_slots;
     uint64_t blend_budget_slots = 48ull << 20;  // fragment-list slots (32 B each) a frame may use at once; RDR_BLEND_BUDGET_SLOTS overrides (tests)  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
 
+    // Shadow views whose inputs did not change are not rendered again. `geometry_version` counts every call that can
+    // move or add geometry (rdr_add_mesh, rdr_set_mesh_transform, rdr_set_mesh_joints), `lights_version` every
+    // rdr_set_lights. A cascade array (one per frame slot) remembers the version and the cascade matrices it was
+    // rendered with; the point-light faces remember the version, the lights and the slot assignment of the last pass
+    // over the moving primitives.
+    uint64_t geometry_version = 1, lights_version = 1;
+    struct ShadowKey { bool valid = false; uint64_t geometry = 0, lights = 0, hash = 0; };
+    ShadowKey cascades_key[2], point_dynamic_key;
+    uint32_t views_reused = 0;          // shadow views of the frame being enqueued that were left as they are
     bool point_borders_stale = false;   // a face of a point-light cube was (or is about to be) re-rendered: the borders follow
     uint32_t point_cubes_in_use = 0;
     unsigned long long frame_pairs_before = 0;  // (triangle, tile) pairs of the batches of this frame binned so far
@@ -290,6 +312,79 @@ void append_draws(const rdr_ctx* c, const std::vector<uint32_t>& prim_list, cons
         first_tri += pr.tri_count;
         out.push_back(d);
     }
+}
+
+uint64_t hash_words(uint64_t h, const void* data, size_t bytes) {  // 64-bit FNV-1a over 32-bit words
+    const uint32_t* w = (const uint32_t*)data;
+    for (size_t i = 0; i < bytes / 4; i++) { h ^= w[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+enum CandKind { CAND_OPAQUE = 0, CAND_NON_OPAQUE = 1, CAND_STATIC = 2, CAND_DYNAMIC = 3, CAND_EVERY = 4 };
+
+// The draws of one view: appended on the host, or left to the draw-list kernels as one list of candidates (`kind`
+// names the same primitives as `prim_list`). `view` must be the index the view has, or is about to get, in b.views.
+void add_view_draws(rdr_ctx* c, Batch& b, CandKind kind, const std::vector<uint32_t>& prim_list, const mat4& viewproj, vec3 eye, SortMode mode,
+                    uint32_t view, bool drop_empty) {
+    if (!c->device_draws) { append_draws(c, prim_list, viewproj, eye, mode, view, b.draws); return; }
+    DDrawList l;
+    memset(&l, 0, sizeof l);
+    memcpy(l.viewproj, viewproj.m, 64);
+    l.eye[0] = eye.x; l.eye[1] = eye.y; l.eye[2] = eye.z;
+    l.sort = mode == SORT_FRONT_TO_BACK ? 1u : (mode == SORT_BACK_TO_FRONT ? 2u : 0u);
+    l.cand_first = kind == CAND_EVERY ? RDR_CAND_ALL : c->cand_first[kind];
+    l.cand_count = kind == CAND_EVERY ? (uint32_t)c->prims.size() : c->cand_count[kind];
+    l.view = view;
+    l.drop_empty = drop_empty ? 1u : 0u;
+    l.kind = (uint32_t)kind;
+    b.lists.push_back(l);
+}
+
+// Tables the draw-list kernels read: box / barycentre / size of every primitive, the model matrix of every mesh and
+// the four candidate lists. Rebuilt once per frame (boxes of skinned primitives and model matrices move).
+int upload_cull_tables(rdr_ctx* c) {
+    if (c->cull_tables_frame == c->frames) return RDR_OK;
+    c->cull_tables_frame = c->frames;
+    const size_t np = c->prims.size(), nm = c->meshes.size();
+    auto round16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t sz_p = round16(np * sizeof(DPrimCull)), sz_m = round16(nm * 64), sz_c = round16(2 * np * 4);
+    HIP_TRY(c->h_cull.ensure(sz_p + sz_m + sz_c + 64));
+    uint8_t* st = c->h_cull.as<uint8_t>();
+    DPrimCull* pc = (DPrimCull*)st;
+    float* mm = (float*)(st + sz_p);
+    uint32_t* cand = (uint32_t*)(st + sz_p + sz_m);
+    uint32_t n_kind[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 5; k++) c->cand_tris[k] = 0;
+    for (size_t p = 0; p < np; p++) {
+        const HostPrim& hp = c->prims[p];
+        DPrimCull& d = pc[p];
+        d.bb_min[0] = hp.bb_min.x; d.bb_min[1] = hp.bb_min.y; d.bb_min[2] = hp.bb_min.z;
+        d.bb_max[0] = hp.bb_max.x; d.bb_max[1] = hp.bb_max.y; d.bb_max[2] = hp.bb_max.z;
+        d.barycenter[0] = hp.barycenter.x; d.barycenter[1] = hp.barycenter.y; d.barycenter[2] = hp.barycenter.z;
+        d.mesh = hp.mesh; d.tri_count = hp.tri_count; d.n_chunks = (hp.tri_count + RDR_CHUNK_TRIS - 1u) / RDR_CHUNK_TRIS;
+        n_kind[hp.mat.alpha_mode == RDR_ALPHA_OPAQUE ? CAND_OPAQUE : CAND_NON_OPAQUE]++;
+        n_kind[c->meshes[hp.mesh].is_static ? CAND_STATIC : CAND_DYNAMIC]++;
+    }
+    // opaque | non-opaque share the first np entries, static | dynamic the second np
+    c->cand_first[CAND_OPAQUE] = 0; c->cand_first[CAND_NON_OPAQUE] = n_kind[CAND_OPAQUE];
+    c->cand_first[CAND_STATIC] = (uint32_t)np; c->cand_first[CAND_DYNAMIC] = (uint32_t)np + n_kind[CAND_STATIC];
+    uint32_t fill[4] = {0, 0, 0, 0};
+    for (size_t p = 0; p < np; p++) {
+        const HostPrim& hp = c->prims[p];
+        const int a = hp.mat.alpha_mode == RDR_ALPHA_OPAQUE ? CAND_OPAQUE : CAND_NON_OPAQUE, m = c->meshes[hp.mesh].is_static ? CAND_STATIC : CAND_DYNAMIC;
+        cand[c->cand_first[a] + fill[a]++] = (uint32_t)p;
+        cand[c->cand_first[m] + fill[m]++] = (uint32_t)p;
+        c->cand_tris[a] += hp.tri_count; c->cand_tris[m] += hp.tri_count; c->cand_tris[CAND_EVERY] += hp.tri_count;
+    }
+    for (int k = 0; k < 4; k++) c->cand_count[k] = n_kind[k];
+    for (size_t m = 0; m < nm; m++) memcpy(mm + m * 16, c->meshes[m].model.m, 64);
+    HIP_TRY(c->d_prim_cull.ensure(std::max<size_t>(sz_p, 16)));
+    HIP_TRY(c->d_models.ensure(std::max<size_t>(sz_m, 16)));
+    HIP_TRY(c->d_cand.ensure(std::max<size_t>(sz_c, 16)));
+    if (sz_p) HIP_TRY(hipMemcpyAsync(c->d_prim_cull.p, pc, sz_p, hipMemcpyHostToDevice, c->stream));
+    if (sz_m) HIP_TRY(hipMemcpyAsync(c->d_models.p, mm, sz_m, hipMemcpyHostToDevice, c->stream));
+    if (sz_c) HIP_TRY(hipMemcpyAsync(c->d_cand.p, cand, sz_c, hipMemcpyHostToDevice, c->stream));
+    return RDR_OK;
 }
 
 // VulkanRendererShadow.cpp:152-175
@@ -516,40 +611,104 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
         v.tile_base = n_tiles;
         n_tiles += v.tiles_x * v.tiles_y;
     }
-    const uint32_t n_draws = (uint32_t)b.draws.size();
-    std::vector<uint32_t> draw_first(n_draws + 1, 0), first_tri(n_draws + 1, 0), chunk_first(n_draws + 1, 0);
-    uint64_t inst64 = 0;
-    uint32_t n_chunks = 0;  // one flag per RDR_CHUNK_TRIS triangle instances of a draw: at most 2^26 + one per draw
-    for (uint32_t i = 0; i < n_draws; i++) {
-        b.draws[i].first_instance = (uint32_t)inst64;
-        draw_first[i] = (uint32_t)inst64;
-        first_tri[i] = b.draws[i].first_tri_id;
-        chunk_first[i] = n_chunks;
-        inst64 += c->prims[b.draws[i].prim].tri_count;
-        n_chunks += (c->prims[b.draws[i].prim].tri_count + RDR_CHUNK_TRIS - 1u) / RDR_CHUNK_TRIS;
-    }
-    chunk_first[n_draws] = n_chunks;
-    if (inst64 >= 0xFFFFFFF0ull) return fail(c, RDR_ERR_CAPACITY, "more than 2^32 triangle instances in one batch");
-    const uint32_t n_inst = (uint32_t)inst64;
-    c->batch_instances = n_inst;
-    draw_first[n_draws] = n_inst;
-    // stage the tables in pinned memory and upload
     auto round16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t sz_views = round16(b.views.size() * sizeof(DView)), sz_draws = round16(std::max<size_t>(n_draws, 1) * sizeof(DDraw)),
-                 sz_first = round16((n_draws + 1) * 4);
-    const size_t sz_tables = sz_views + sz_draws + 3 * sz_first;
-    HIP_TRY(c->h_stage.ensure(sz_tables + 64));
-    uint8_t* st = c->h_stage.as<uint8_t>();
-    memcpy(st, b.views.data(), b.views.size() * sizeof(DView));
-    if (n_draws) memcpy(st + sz_views, b.draws.data(), n_draws * sizeof(DDraw));
-    memcpy(st + sz_views + sz_draws, draw_first.data(), (n_draws + 1) * 4);
-    memcpy(st + sz_views + sz_draws + sz_first, first_tri.data(), (n_draws + 1) * 4);
-    memcpy(st + sz_views + sz_draws + 2 * sz_first, chunk_first.data(), (n_draws + 1) * 4);
-    HIP_TRY(c->d_batch_tables.ensure(sz_tables));
-    uint8_t* dt = c->d_batch_tables.as<uint8_t>();
-    c->d_views.p = dt; c->d_draws.p = dt + sz_views; c->d_draw_first.p = dt + sz_views + sz_draws;
-    c->d_first_tri.p = dt + sz_views + sz_draws + sz_first; c->d_chunk_first.p = dt + sz_views + sz_draws + 2 * sz_first;
-    HIP_TRY(hipMemcpyAsync(dt, st, sz_tables, hipMemcpyHostToDevice, c->stream));
+    uint32_t n_draws = 0, n_inst = 0, n_chunks = 0;  // n_chunks: one flag per RDR_CHUNK_TRIS triangle instances of a draw
+    b.info.assign(b.views.size(), DDrawListInfo{0, 0, 0, 0});
+    b.views_dropped = 0;
+    if (!c->device_draws) {
+        n_draws = (uint32_t)b.draws.size();
+        std::vector<uint32_t> draw_first(n_draws + 1, 0), first_tri(n_draws + 1, 0), chunk_first(n_draws + 1, 0);
+        uint64_t inst64 = 0;
+        for (uint32_t i = 0; i < n_draws; i++) {
+            DDraw& d = b.draws[i];
+            DDrawListInfo& vi = b.info[d.view];
+            if (vi.n_draws == 0) { vi.first_draw = i; vi.first_instance = (uint32_t)inst64; }
+            vi.n_draws++;
+            vi.n_tris += c->prims[d.prim].tri_count;
+            d.first_instance = (uint32_t)inst64;
+            draw_first[i] = (uint32_t)inst64;
+            first_tri[i] = d.first_tri_id;
+            chunk_first[i] = n_chunks;
+            inst64 += c->prims[d.prim].tri_count;
+            n_chunks += (c->prims[d.prim].tri_count + RDR_CHUNK_TRIS - 1u) / RDR_CHUNK_TRIS;
+        }
+        chunk_first[n_draws] = n_chunks;
+        if (inst64 >= 0xFFFFFFF0ull) return fail(c, RDR_ERR_CAPACITY, "more than 2^32 triangle instances in one batch");
+        n_inst = (uint32_t)inst64;
+        draw_first[n_draws] = n_inst;
+        // stage the tables in pinned memory and upload
+        const size_t sz_views = round16(b.views.size() * sizeof(DView)), sz_draws = round16(std::max<size_t>(n_draws, 1) * sizeof(DDraw)),
+                     sz_first = round16((n_draws + 1) * 4);
+        const size_t sz_tables = sz_views + sz_draws + 3 * sz_first;
+        HIP_TRY(c->h_stage.ensure(sz_tables + 64));
+        uint8_t* st = c->h_stage.as<uint8_t>();
+        memcpy(st, b.views.data(), b.views.size() * sizeof(DView));
+        if (n_draws) memcpy(st + sz_views, b.draws.data(), n_draws * sizeof(DDraw));
+        memcpy(st + sz_views + sz_draws, draw_first.data(), (n_draws + 1) * 4);
+        memcpy(st + sz_views + sz_draws + sz_first, first_tri.data(), (n_draws + 1) * 4);
+        memcpy(st + sz_views + sz_draws + 2 * sz_first, chunk_first.data(), (n_draws + 1) * 4);
+        HIP_TRY(c->d_batch_tables.ensure(sz_tables));
+        uint8_t* dt = c->d_batch_tables.as<uint8_t>();
+        c->d_views.p = dt; c->d_draws.p = dt + sz_views; c->d_draw_first.p = dt + sz_views + sz_draws;
+        c->d_first_tri.p = dt + sz_views + sz_draws + sz_first; c->d_chunk_first.p = dt + sz_views + sz_draws + 2 * sz_first;
+        HIP_TRY(hipMemcpyAsync(dt, st, sz_tables, hipMemcpyHostToDevice, c->stream));
+    } else {
+        // the draw-list kernels fill the same tables; the host uploads views and lists and reads back the sizes
+        const uint32_t n_lists = (uint32_t)b.lists.size();
+        uint64_t slots64 = 0, tris64 = 0;
+        uint32_t longest_sorted = 0;
+        for (DDrawList& l : b.lists) {
+            l.slot_base = (uint32_t)slots64;
+            slots64 += l.cand_count;
+            if (l.sort) longest_sorted = std::max(longest_sorted, l.cand_count);
+            tris64 += c->cand_tris[l.kind];  // an upper bound: every candidate survives
+        }
+        if (slots64 >= 0xFFFFFFF0ull) return fail(c, RDR_ERR_CAPACITY, "more than 2^32 (view, primitive) candidates in one batch");
+        if (tris64 >= 0xFFFFFFF0ull) return fail(c, RDR_ERR_CAPACITY, "more than 2^32 triangle instances in one batch");
+        const uint32_t n_slots = (uint32_t)slots64;
+        const size_t sz_views = round16(b.views.size() * sizeof(DView)), sz_lists = round16(std::max<size_t>(n_lists, 1) * sizeof(DDrawList)),
+                     sz_draws = round16(std::max<size_t>(n_slots, 1) * sizeof(DDraw)), sz_first = round16(((size_t)n_slots + 1) * 4),
+                     sz_info = round16(std::max<size_t>(n_lists, 1) * sizeof(DDrawListInfo)) + 64;
+        const size_t sz_tables = sz_views + sz_lists + sz_draws + 3 * sz_first + sz_info;
+        HIP_TRY(c->h_stage.ensure(sz_views + sz_lists + 64));
+        uint8_t* st = c->h_stage.as<uint8_t>();
+        memcpy(st, b.views.data(), b.views.size() * sizeof(DView));
+        if (n_lists) memcpy(st + sz_views, b.lists.data(), n_lists * sizeof(DDrawList));
+        HIP_TRY(c->d_batch_tables.ensure(sz_tables));
+        uint8_t* dt = c->d_batch_tables.as<uint8_t>();
+        c->d_views.p = dt;
+        uint8_t* d_lists = dt + sz_views;
+        c->d_draws.p = d_lists + sz_lists; c->d_draw_first.p = (uint8_t*)c->d_draws.p + sz_draws;
+        c->d_first_tri.p = (uint8_t*)c->d_draw_first.p + sz_first; c->d_chunk_first.p = (uint8_t*)c->d_first_tri.p + sz_first;
+        uint8_t* d_info = (uint8_t*)c->d_chunk_first.p + sz_first;                                   // n_lists records, then ...
+        uint32_t* d_totals = (uint32_t*)(d_info + sz_info - 64);                                     // ... {draws, instances, chunks}
+        HIP_TRY(hipMemcpyAsync(dt, st, sz_views + sz_lists, hipMemcpyHostToDevice, c->stream));
+        std::vector<DDrawListInfo> info(n_lists);
+        uint32_t totals[3] = {0, 0, 0};
+        if (n_lists) {
+            HIP_TRY(c->d_draw_scratch.ensure(draw_list_scratch_words(n_slots, longest_sorted) * 4));
+            HIP_TRY(c->d_hist.ensure((sort_hist_words(std::max(longest_sorted, 1u)) + 16) * 4));
+            HIP_TRY(c->d_scan.ensure((std::max(scan_scratch_words(std::max(n_slots, 1u)), scan_scratch_words((uint32_t)sort_hist_words(std::max(longest_sorted, 1u)))) + 16) * 4));
+            launch_draw_lists(c->stream, b.lists.data(), n_lists, (const DDrawList*)d_lists, n_slots, c->d_prim_cull.as<DPrimCull>(), c->d_models.as<float>(),
+                              c->d_cand.as<uint32_t>(), c->d_draw_scratch.as<uint32_t>(), c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(),
+                              c->d_draws.as<DDraw>(), c->d_draw_first.as<uint32_t>(), c->d_first_tri.as<uint32_t>(), c->d_chunk_first.as<uint32_t>(),
+                              (DDrawListInfo*)d_info, c->d_views.as<DView>(), d_totals);
+            // the sizes of everything downstream: one small copy, and the host waits for it
+            std::vector<uint8_t> back(sz_info);
+            HIP_TRY(hipMemcpyAsync(back.data(), d_info, sz_info, hipMemcpyDeviceToHost, c->stream));
+            const double t_wait = host_now();
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->host_wait_s += host_now() - t_wait;
+            memcpy(info.data(), back.data(), n_lists * sizeof(DDrawListInfo));
+            memcpy(totals, back.data() + sz_info - 64, 12);
+        }
+        n_draws = totals[0]; n_inst = totals[1]; n_chunks = totals[2];
+        for (uint32_t l = 0; l < n_lists; l++) {
+            b.info[b.lists[l].view] = info[l];
+            if (b.lists[l].drop_empty && info[l].n_draws == 0) b.views_dropped++;
+        }
+    }
+    c->batch_instances = n_inst;
     HIP_TRY(c->d_chunk_flags.ensure(std::max<size_t>(n_chunks, 16)));
     HIP_TRY(c->d_recs.ensure(std::max<size_t>(n_inst, 1) * sizeof(DTriRec)));
     HIP_TRY(c->d_pair_count.ensure(std::max<size_t>(n_inst, 1) * 4));
@@ -622,7 +781,7 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     }
     c->stats.triangle_instances += n_inst;
     c->stats.tile_pairs += n_pairs;
-    c->stats.views += (uint32_t)b.views.size();
+    c->stats.views += (uint32_t)b.views.size() - b.views_dropped;
     *out_tiles = n_tiles;
     *out_cur = cur;
     return RDR_OK;
@@ -707,6 +866,7 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
     const uint32_t res = c->settings.point_shadow_map_resolution, pitch = res + 2;
     const size_t face_px = point_face_texels(c), origin = point_face_origin(c), total_bytes = face_px * 6 * count * 4;
     if (c->d_point_shadow.cap < total_bytes) {
+        c->point_dynamic_key.valid = false;
         HIP_TRY(c->d_point_shadow.ensure(total_bytes));
         HIP_TRY(c->d_point_static.ensure(total_bytes));
         launch_fill_f32(c->stream, c->d_point_shadow.as<float>(), 1.0f, face_px * 6 * count);
@@ -754,7 +914,7 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
             const mat4 vp = face[j].view_proj();
             float* dst = c->d_point_static.as<float>() + ((size_t)l.slot * 6 + j) * face_px + origin;
             sb.views.push_back(make_view(dst, nullptr, res, res, 1, 1, 0, nullptr, pitch));
-            append_draws(c, static_prims, vp, l.point, SORT_FRONT_TO_BACK, (uint32_t)sb.views.size() - 1, sb.draws);
+            add_view_draws(c, sb, CAND_STATIC, static_prims, vp, l.point, SORT_NONE, (uint32_t)sb.views.size() - 1, false);
         }
         l.flags |= RDR_POINT_LIGHT_STATIC_SHADOW_MAP_RENDERED;
         refreshed.push_back(i);
@@ -770,6 +930,20 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
         c->point_borders_stale = true;
     }
     c->point_cubes_in_use = (uint32_t)slotted.size();
+    // The pass over the moving primitives is a function of the lights in the slots, the static maps and the geometry:
+    // if none of them changed since the last frame, the faces already hold what it would write.
+    {
+        rdr_ctx::ShadowKey& key = c->point_dynamic_key;
+        uint64_t h = hash_words(14695981039346656037ull, &res, 4);
+        for (uint32_t i : slotted) { h = hash_words(h, &i, 4); h = hash_words(h, &c->lights[i].point, 12); }
+        const uint32_t dyn = c->settings.dynamic_shadows_enabled;
+        h = hash_words(h, &dyn, 4);
+        if (refreshed.empty() && key.valid && key.geometry == c->geometry_version && key.lights == c->lights_version && key.hash == h) {
+            c->views_reused += 6 * (uint32_t)slotted.size();
+            return RDR_OK;
+        }
+        key.valid = true; key.geometry = c->geometry_version; key.lights = c->lights_version; key.hash = h;
+    }
     // dynamic meshes on top of the static face: the rasteriser starts every tile of such a face from the cached static
     // map (DView::init) and writes the result to the map the shaders read, so the static map is never copied
     for (uint32_t i : slotted) {
@@ -777,15 +951,16 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
         for (int j = 0; j < 6; j++) {
             face[j].position = l.point;
             const mat4 vp = face[j].view_proj();
+            if (!c->settings.dynamic_shadows_enabled || dynamic_prims.empty()) continue;
+            // a face is rendered again only if a moving primitive is in its frustum (VulkanRendererShadow.cpp:337-342);
+            // otherwise it keeps what it holds
             const size_t n_before = dynamic_batch.draws.size();
-            append_draws(c, dynamic_prims, vp, l.point, SORT_FRONT_TO_BACK, (uint32_t)dynamic_batch.views.size(), dynamic_batch.draws);
-            if (c->settings.dynamic_shadows_enabled && dynamic_batch.draws.size() > n_before) {
+            add_view_draws(c, dynamic_batch, CAND_DYNAMIC, dynamic_prims, vp, l.point, SORT_NONE, (uint32_t)dynamic_batch.views.size(), true);
+            if (c->device_draws || dynamic_batch.draws.size() > n_before) {
                 const size_t off = ((size_t)l.slot * 6 + j) * face_px + origin;
                 dynamic_batch.views.push_back(make_view(c->d_point_shadow.as<float>() + off, nullptr, res, res, 1, 1, 1,
                                                         c->d_point_static.as<float>() + off, pitch));
                 c->point_borders_stale = true;
-            } else {
-                dynamic_batch.draws.resize(n_before);
             }
         }
     }
@@ -797,6 +972,7 @@ int cascade_views(rdr_ctx* c, Batch& b) {
     const uint32_t levels = c->settings.directional_shadow_cascade_levels, res = c->settings.directional_shadow_map_resolution;
     const size_t px = cascade_texels(c);
     if (c->d_dir_shadow.cap < px * levels * 4) {
+        c->cascades_key[c->slot].valid = false;
         HIP_TRY(c->d_dir_shadow.ensure(px * levels * 4));
         launch_fill_f32(c->stream, c->d_dir_shadow.as<float>(), 1.0f, px * levels);  // the border keeps this value; the rasteriser writes the interior
     }
@@ -811,6 +987,7 @@ int cascade_views(rdr_ctx* c, Batch& b) {
     std::vector<uint32_t> all(c->prims.size());
     for (uint32_t p = 0; p < all.size(); p++) all[p] = p;
     static const float ndc[8][3] = {{-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1}};
+    vec3 eye[RDR_MAX_CASCADES];
     for (uint32_t i = 0; i < levels; i++) {
         Camera split = c->camera;  // the reference's Camera copy drops the crop matrix (Camera.cpp:3-41)
         split.crop = mat_identity();
@@ -829,10 +1006,21 @@ int cascade_views(rdr_ctx* c, Batch& b) {
         const vec3 offset = make3(-((mx[0] + mn[0]) / 2), -((mx[1] + mn[1]) / 2), -0.0f);
         Camera split_pov = light;
         split_pov.crop = mat_mul(mat_scale(make3(1.0f / largest, 1.0f / largest, 1.0f)), mat_translate(offset));
-        const mat4 vp = split_pov.view_proj();
-        c->csm_viewproj[i] = vp;
+        c->csm_viewproj[i] = split_pov.view_proj();
+        eye[i] = split_pov.position;
+    }
+    // The reference draws every cascade every frame (VulkanRendererShadow.cpp:424). The array of this frame slot
+    // still holds the cascades of two frames ago: if nothing that goes into them has changed since (same matrices,
+    // no mesh added or moved), they are what this frame would render, and are left alone.
+    rdr_ctx::ShadowKey& key = c->cascades_key[c->slot];
+    uint64_t h = hash_words(14695981039346656037ull, &levels, 4);
+    h = hash_words(h, &res, 4);
+    for (uint32_t i = 0; i < levels; i++) h = hash_words(h, c->csm_viewproj[i].m, 64);
+    if (key.valid && key.geometry == c->geometry_version && key.hash == h) { c->views_reused += levels; return RDR_OK; }
+    key.valid = true; key.geometry = c->geometry_version; key.hash = h;
+    for (uint32_t i = 0; i < levels; i++) {
         b.views.push_back(make_view(c->d_dir_shadow.as<float>() + (size_t)i * px + cascade_origin(c), nullptr, res, res, 1, 1, 0, nullptr, res + 4));
-        append_draws(c, all, vp, split_pov.position, SORT_FRONT_TO_BACK, (uint32_t)b.views.size() - 1, b.draws);
+        add_view_draws(c, b, CAND_EVERY, all, c->csm_viewproj[i], eye[i], SORT_NONE, (uint32_t)b.views.size() - 1, false);
     }
     return RDR_OK;
 }
@@ -1195,6 +1383,7 @@ int rdr_add_mesh(rdr_ctx* c, const rdr_primitive_desc* descs, uint32_t count, co
     mesh.joints.assign((size_t)mesh.n_joints * 16, 0.0f);
     for (uint32_t j = 0; j < mesh.n_joints; j++) mesh.joints[j * 16] = mesh.joints[j * 16 + 5] = mesh.joints[j * 16 + 10] = mesh.joints[j * 16 + 15] = 1.0f;
     c->meshes.push_back(mesh);
+    c->geometry_version++;
     c->geometry_dirty = true;
     if (out_mesh_id) *out_mesh_id = mesh_id;
     return RDR_OK;
@@ -1203,6 +1392,7 @@ int rdr_add_mesh(rdr_ctx* c, const rdr_primitive_desc* descs, uint32_t count, co
 int rdr_set_mesh_transform(rdr_ctx* c, uint32_t mesh_id, const float model[16]) {
     if (!c || !model || mesh_id >= c->meshes.size()) return fail(c, RDR_ERR_INVALID, "set_mesh_transform: bad argument");
     memcpy(c->meshes[mesh_id].model.m, model, 64);
+    c->geometry_version++;
     return RDR_OK;
 }
 
@@ -1213,6 +1403,7 @@ int rdr_set_mesh_joints(rdr_ctx* c, uint32_t mesh_id, const float* jm, uint32_t 
     if (count < mesh.n_joints) return fail(c, RDR_ERR_INVALID, "set_mesh_joints: fewer matrices than the largest joint index in use");
     memcpy(mesh.joints.data(), jm, (size_t)mesh.n_joints * 64);
     c->skin_dirty = true;
+    c->geometry_version++;
     // culling box of each skinned primitive: around its rest box carried by every joint
     for (uint32_t pi = mesh.first_prim; pi < mesh.first_prim + mesh.prim_count; pi++) {
         HostPrim& p = c->prims[pi];
@@ -1262,6 +1453,7 @@ int rdr_set_lights(rdr_ctx* c, const rdr_point_light* lights, uint32_t count, co
     }
     c->dir_light = *dl;
     c->lights_set = true;
+    c->lights_version++;
     compute_cascade_splits(c);
     return RDR_OK;
 }
@@ -1450,7 +1642,13 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     c->stats = rdr_frame_stats{};
     c->stats.frame_index = ++c->frames;
     c->frame_pairs_before = 0;
+    c->views_reused = 0;
+    {
+        const char* e = getenv("RDR_DEVICE_DRAW_LISTS");
+        c->device_draws = e ? atoi(e) != 0 : c->prims.size() >= 2048;
+    }
     HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_BYTES, c->stream));
+    if (c->device_draws) RDR_TRY(upload_cull_tables(c));  // the candidate lists the views below refer to
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const vec3 cam_pos = c->camera.position;
     const mat4 viewproj = c->camera.view_proj();
@@ -1467,32 +1665,31 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     for (uint32_t p = 0; p < c->prims.size(); p++) (c->prims[p].mat.alpha_mode == RDR_ALPHA_OPAQUE ? opaque : non_opaque).push_back(p);
     const uint32_t main_view = (uint32_t)b.views.size();
     b.views.push_back(make_view(c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), W, H, S, 2, 0));
-    const size_t first_main_draw = b.draws.size();
-    append_draws(c, opaque, viewproj, cam_pos, SORT_FRONT_TO_BACK, main_view, b.draws);
-    const size_t n_main_draws = b.draws.size() - first_main_draw;
-    c->main_draws.assign(b.draws.begin() + first_main_draw, b.draws.end());
-    const size_t first_blend_draw = b.draws.size();
-    append_draws(c, non_opaque, viewproj, cam_pos, SORT_BACK_TO_FRONT, main_view + 1, b.draws);
-    const size_t n_blend_draws = b.draws.size() - first_blend_draw;
-    const bool have_blend = n_blend_draws != 0;
-    if (have_blend) b.views.push_back(make_view(c->d_depth.as<float>(), nullptr, W, H, S, 2, 2));
-    c->stats.draws_main = (uint32_t)(n_main_draws + n_blend_draws);
+    // the order of these two lists shows: visibility ids follow it, the earlier draw keeps a depth tie, blending is
+    // back to front (VulkanRenderer.cpp:945-963)
+    add_view_draws(c, b, CAND_OPAQUE, opaque, viewproj, cam_pos, SORT_FRONT_TO_BACK, main_view, false);
+    const size_t draws_before_blend = b.draws.size();
+    if (!non_opaque.empty()) add_view_draws(c, b, CAND_NON_OPAQUE, non_opaque, viewproj, cam_pos, SORT_BACK_TO_FRONT, main_view + 1, false);
+    // the blended "view" exists when blended draws do (host path) or may (device path: their number comes back later)
+    const bool blend_view = c->device_draws ? !non_opaque.empty() : b.draws.size() > draws_before_blend;
+    if (blend_view) b.views.push_back(make_view(c->d_depth.as<float>(), nullptr, W, H, S, 2, 2));
     // Frame constants, then the vertex stage of the main view's triangles: enqueued from inside the batch, right after
     // its pair scan (which is all k_shade_setup needs from it), so that they run while the host waits for the pair count.
+    size_t first_main_draw = 0, n_main_draws = 0, first_blend_draw = 0, n_blend_draws = 0;
+    bool have_blend = false;
     uint32_t main_first_instance = 0, n_main_tris = 0, blend_first_instance = 0, n_blend_tris = 0;
     DShadeTri *tris_main = nullptr, *tris_blend = nullptr;
     auto enqueue_shade_setup = [&]() -> int {
-        // triangle records of a view are contiguous in d_recs, in visibility-id order
-        if (n_main_draws) {
-            main_first_instance = b.draws[first_main_draw].first_instance;
-            const DDraw& last = b.draws[first_blend_draw - 1];
-            n_main_tris = last.first_tri_id + c->prims[last.prim].tri_count;
+        // where the batch's tables hold the two lists (triangle records of a view are contiguous in d_recs, in
+        // visibility-id order)
+        const DDrawListInfo& mi = b.info[main_view];
+        first_main_draw = mi.first_draw; n_main_draws = mi.n_draws; main_first_instance = mi.first_instance; n_main_tris = mi.n_tris;
+        if (blend_view) {
+            const DDrawListInfo& bi = b.info[main_view + 1];
+            first_blend_draw = bi.first_draw; n_blend_draws = bi.n_draws; blend_first_instance = bi.first_instance; n_blend_tris = bi.n_tris;
         }
-        if (have_blend) {
-            blend_first_instance = b.draws[first_blend_draw].first_instance;
-            const DDraw& last = b.draws.back();
-            n_blend_tris = last.first_tri_id + c->prims[last.prim].tri_count;
-        }
+        have_blend = n_blend_draws != 0;
+        c->stats.draws_main = (uint32_t)(n_main_draws + n_blend_draws);
         DFrame fr;
         memset(&fr, 0, sizeof fr);
         fr.W = W; fr.H = H; fr.samples = S; fr.n_lights = (uint32_t)c->lights.size();
@@ -1551,9 +1748,9 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     };
     int cur = 0;
     RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup));
-    if (have_blend) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
+    if (blend_view) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    const uint32_t blend_tile_base = have_blend ? b.views.back().tile_base : 0u;
+    const uint32_t blend_tile_base = blend_view ? b.views.back().tile_base : 0u;
 
     // ---- opaque shading + skybox
     if (S == 4 && have_blend) HIP_TRY(c->d_samples.ensure(n * 4 * 8));
@@ -1643,6 +1840,8 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     HIP_TRY(hipEventRecord(c->ev[5], c->stream4));
     // host time of this frame: everything this call did up to here, less the time it sat waiting for the GPU
     c->stats.host_ms = (float)((host_now() - t_enter - c->host_wait_s) * 1e3);
+    c->stats.views_reused = c->views_reused;
+    c->stats.draw_lists_on_device = c->device_draws ? 1u : 0u;
     c->pending[c->slot].on = true;
     c->pending[c->slot].host = c->stats;
     // The frame before this one has had the whole set-up of this one to finish its tail: its results are picked up
@@ -1671,6 +1870,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream4);
         (void)hipGetLastError();
         c->pending[c->slot].on = false;
+        c->cascades_key[0].valid = c->cascades_key[1].valid = c->point_dynamic_key.valid = false;  // targets may be half written
         harvest(c, c->slot ^ 1);
         c->err = keep;
     }

@@ -60,7 +60,8 @@ struct DView {
     uint32_t cull;       // 0 none, 1 front, 2 back
     uint32_t tiles_x, tiles_y;
     uint32_t tile_base;  // first global tile id of this view
-    uint32_t load;       // 0: start from depth 1.0, 1: start from what `init` holds, 2: binned only (the blended pass rasterises it)
+    uint32_t load;       // 0: start from depth 1.0, 1: start from what `init` holds, 2: binned only (the blended pass rasterises it),
+                         // 3: skipped (set on the GPU for a view whose draw list came out empty, DDrawList::drop_empty)
     uint32_t pitch;      // texels from one row of depth / init / vis to the next (>= w: shadow targets carry a border the shaders filter across)
 };
 
@@ -73,6 +74,35 @@ struct DDraw {
     uint32_t first_instance;  // global index of its first triangle instance in this batch
     uint32_t first_tri_id;    // running triangle index inside its view (the visibility id)
 };
+
+// What the draw-list kernels need of a primitive: the box and barycentre drawMeshes culls and orders by
+// (Renderer/VulkanRenderer.cpp:929-999), its mesh (for the model matrix) and how much it adds to the batch.
+struct DPrimCull {
+    float bb_min[3], bb_max[3], barycenter[3];
+    uint32_t mesh;
+    uint32_t tri_count;
+    uint32_t n_chunks;  // ceil(tri_count / RDR_CHUNK_TRIS)
+};  // 48 bytes
+
+#define RDR_CAND_ALL 0xFFFFFFFFu  // DDrawList::cand_first: the candidates are all primitives, in index order
+
+// One view's candidate primitives: which of them survive the frustum test, and in what order they are drawn, is
+// decided on the GPU. Candidate j of list l owns slot slot_base + j of the batch.
+struct DDrawList {
+    float viewproj[16];
+    float eye[3];
+    uint32_t sort;        // 0: candidate order, 1: nearest barycentre first, 2: farthest first (both stable)
+    uint32_t cand_first;  // first entry in the candidate array, or RDR_CAND_ALL
+    uint32_t cand_count;
+    uint32_t slot_base;
+    uint32_t view;        // the view (index into the batch's DView table) the surviving draws belong to
+    uint32_t drop_empty;  // 1: a view without a surviving draw is not rendered at all (its target keeps what it holds)
+    uint32_t kind;        // host bookkeeping: which candidate list this is
+    uint32_t _pad[2];
+};  // 112 bytes
+
+// per list, written by the draw-list kernels and read back by the host
+struct DDrawListInfo { uint32_t first_draw, n_draws, first_instance, n_tris; };
 
 // Output of triangle set-up: the snapped clip polygon and its depth plane.
 struct DTriRec {

@@ -544,6 +544,47 @@ def sponza_like(r, tex_size=1024, env_res=256, detail=1.0, n_materials=25, seed=
     return ids
 
 
+def many_primitives(r, side=100, tex_size=32, env_res=16, seed=9):
+    """side x side small boxes on a floor, every one a mesh of its own with one primitive (12 triangles): what a scene
+    exported object by object looks like to drawMeshes. Every 10th box is a dynamic node, every 7th blends, every
+    11th is alpha-masked. The grid is mirror-symmetric about x = 0, so with a camera on that plane pairs of boxes
+    have equal barycentre distances and the stable order of the draw lists shows. Returns the mesh ids by kind."""
+    rng = np.random.default_rng(seed)
+    tex = [material_textures(r, tex_size, 300 + 10 * i, tint=tuple(0.5 + 0.5 * rng.random(3)), metal_fraction=0.3) for i in range(4)]
+    alpha = value_noise(tex_size, 78, octaves=2, base=4)
+    t_mask = material_textures(r, tex_size, 341, tint=(0.5, 1.0, 0.5), alpha=(alpha > 0.45).astype(np.float32))
+    t_blend = material_textures(r, tex_size, 351, tint=(0.6, 0.7, 1.0), alpha=0.3 + 0.4 * alpha)
+    pitch = 0.5
+    half = (side - 1) * pitch / 2
+    ids = {"static": [], "dynamic": [], "floor": r.add_mesh([upload_primitive(r, plane(side * pitch + 4, side * pitch + 4, 4, 4, uv_scale=8.0),
+                                                                              make_material(tex[0]), B.UINT16)])}
+    unit = box(0.28, 0.28, 0.28, 1)
+    k = 0
+    for iz in range(side):
+        for ix in range(side):
+            h = 0.2 + 0.6 * ((ix * 7 + iz * 13) % 5) / 4.0
+            geo = unit.transformed(translation(0.0, 0.14, 0.0))
+            if k % 7 == 3:
+                m = make_material(t_blend, alpha_mode=B.ALPHA_BLEND)
+            elif k % 11 == 5:
+                m = make_material(t_mask, alpha_mode=B.ALPHA_MASK, alpha_cutoff=0.5)
+            else:
+                m = make_material(tex[k % 4], base_color=(0.6 + 0.4 * ((k * 5) % 3) / 2.0, 1.0, 1.0, 1.0))
+            dynamic = k % 10 == 4
+            model = translation(ix * pitch - half, h if dynamic else 0.0, iz * pitch - half)
+            mid = r.add_mesh([upload_primitive(r, geo, m, B.UINT16)], model=model.T, is_static=not dynamic)
+            ids["dynamic" if dynamic else "static"].append((mid, ix, iz))
+            k += 1
+    r.set_brdf_lut(brdf_lut(32, 32))
+    r.set_environment_map(sky_faces(env_res))
+    r.set_camera(position=(0.0, 6.0, half + 6.0), euler=(-0.45, 0.0, 0.0))
+    lights = [((0.0, 3.0, 0.0), (60.0, 50.0, 40.0), True), ((-half / 2, 2.5, half / 2), (30.0, 40.0, 60.0), True),
+              ((half / 2, 4.0, -half / 2), (40.0, 40.0, 40.0), False)]
+    r.set_lights(lights, default_directional_light())
+    ids["pitch"], ids["half"] = pitch, half
+    return ids
+
+
 def raster_stress(r, quads_per_side=2236, seed=5):
     """Config-5 stand-in: displaced grid, 2 * quads_per_side^2 triangles, flat material, no textures."""
     n = quads_per_side
