@@ -47,8 +47,15 @@ void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const u
 void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_ranges, uint32_t n_tiles);
 // tiles [first_tile, end_tile) hold the views of one sample count, the first of which is view first_view
 struct RasterRange { uint32_t first_tile, end_tile, first_view; };
-void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange s1, RasterRange s4);
+// the views of one rasteriser launch, passed by value in the kernel arguments
+#define RDR_RASTER_MAX_VIEWS 32
+struct RasterViews {
+    uint32_t n, first_tile;
+    uint32_t base[RDR_RASTER_MAX_VIEWS];  // first tile of view k (0xFFFFFFFF past the last)
+    DView v[RDR_RASTER_MAX_VIEWS];
+};
+void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DView* d_views, const DTriRec* recs, const uint32_t* sorted_vals,
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples);
 
 // kernels_shade.hip
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,

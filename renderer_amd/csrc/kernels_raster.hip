@@ -497,45 +497,48 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 // test in list order leaves (the earlier triangle keeps a tie). The key starts
 // as (initial depth << 32 | 0): a fragment at the initial depth never beats
 // it, as LESS demands.
+// A point-light face that moving meshes are drawn on top of starts from its cached static map (DView::init, load == 1
+// with init != depth). The map is copied to the target in one bandwidth-bound sweep before the face is rasterised, so
+// the tiles without triangles - nearly all of such a face - cost the rasteriser one load of their list bounds.
+// grid: (ceil(max w / 256), max h, views); `views` is the batch's table in device memory (a view the draw-list kernels
+// dropped, load == 3, is left alone).
+__global__ void __launch_bounds__(256) k_view_init(const DView* __restrict__ views, uint32_t first_view) {
+    const DView& vw = views[first_view + blockIdx.z];
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (vw.samples != 1u || vw.load != 1u || vw.init == vw.depth || x >= vw.w || y >= vw.h) return;
+    const size_t at = (size_t)y * vw.pitch + x;
+    vw.depth[at] = vw.init[at];
+}
+
 template <int S, int T, int RASTER_CHUNK>
-__global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, uint32_t n_views, const DTriRec* __restrict__ recs,
-                                              const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ tile_start,
-                                              const uint32_t* __restrict__ tile_end, uint32_t first_view, uint32_t tile_origin) {
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_raster(const RasterViews tbl, const DTriRec* __restrict__ recs, const uint32_t* __restrict__ sorted_vals,
+                                              const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_end) {
     constexpr int Q = 256 / T;  // pixels of the tile per thread: pixel q*T + tid
     static_assert(RASTER_CHUNK <= 64 && (RASTER_CHUNK & (RASTER_CHUNK - 1)) == 0 && RASTER_CHUNK <= T, "one lane of wave 0 per staged record");
-    __shared__ uint32_t lds_rec[RASTER_CHUNK * 32];  // records of 128 bytes
+    __shared__ __attribute__((aligned(16))) uint32_t lds_rec[RASTER_CHUNK * 32];  // records of 128 bytes
     __shared__ uint32_t lds_ids[RASTER_CHUNK];
     __shared__ uint32_t lds_prefix[RASTER_CHUNK + 1];
     __shared__ uint32_t lds_cover[RASTER_CHUNK];     // RASTER_EXACT64 / RASTER_COVER / RASTER_LOCAL32, see below
     __shared__ unsigned long long lds_key[S * 256];  // [sample][pixel of the tile, row-major]
-    const uint32_t tile = tile_origin + blockIdx.x;
-    // A tile's life is a chain of dependent loads, and what a CU gets done is set by the length of that chain: the list
-    // bounds are fetched first, the view table is searched by the lanes of the wave side by side (one round trip, not
-    // one per view), and the first triangle ids are on their way while the view's parameters arrive.
+    const uint32_t tile = tbl.first_tile + blockIdx.x;
+    // A tile's life is a chain of dependent loads, and what a CU gets done is set by the length of that chain. The
+    // views of the launch travel in the kernel arguments (constant memory, no round trip to HBM), and the first
+    // triangle ids are fetched as soon as the list bounds are known.
     const uint32_t begin = tile_start[tile], end = tile_end[tile];
-    // view of this tile: the last one whose first tile is <= tile (views are laid out in order of their tiles)
-    uint32_t v = first_view;
-    for (uint32_t k0 = first_view + 1; k0 < n_views; k0 += 64u) {
-        const uint32_t k = k0 + (threadIdx.x & 63u);
-        const unsigned long long below = __ballot(k < n_views && views[k].tile_base <= tile);
-        if (below) v = k0 + 63u - (uint32_t)__builtin_clzll(below);
-    }
-    v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     uint32_t next_id = 0u;  // triangle id this thread stages for the coming chunk
-    if (begin + threadIdx.x < end && threadIdx.x < (uint32_t)RASTER_CHUNK) next_id = sorted_vals[begin + threadIdx.x];
-    const DView vw = views[v];
-    if ((S == 4) != (vw.samples == 4u)) return;  // the other instantiation handles it
-    if (vw.load >= 2u) return;                    // 2: tiles of the blended pass, binned here, rasterised with their shading; 3: a view that was dropped
+    if (threadIdx.x < (uint32_t)RASTER_CHUNK && begin + threadIdx.x < end) next_id = sorted_vals[begin + threadIdx.x];
+    // view of this tile: the last one whose first tile is <= tile (views are laid out in order of their tiles)
+    uint32_t v = 0;
+    for (uint32_t k = 1; k < tbl.n; k++) if (tbl.base[k] <= tile) v = k;
+    v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    const DView vw = tbl.v[v];
     const uint32_t local_tile = tile - vw.tile_base;
     if (local_tile >= vw.tiles_x * vw.tiles_y) return;
-    // load == 1 with the initial depth in another buffer (a point-light face that starts from its cached static map):
-    // the tile is carried over here, so no separate copy of the map is needed
-    const bool carry = vw.load && vw.init != vw.depth;
-    if (vw.load && !carry && begin >= end) return;  // nothing to add to what the target holds
     const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
     const int tid = (int)threadIdx.x;
     const size_t plane_px = (size_t)vw.pitch * vw.h;
-    if (begin >= end) {                   // nothing drawn here: the tile is just cleared
+    if (begin >= end) {                   // nothing drawn here: the tile is just cleared ...
+        if (S == 1 && vw.load) return;    // ... or, for a view that adds to what its target holds, left as it is
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int pix = q * T + tid, cx = ox0 + (pix & 15), cy = oy0 + (pix >> 4);
@@ -543,7 +546,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
                 const size_t at = (size_t)cy * vw.pitch + cx;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    vw.depth[s * plane_px + at] = carry ? vw.init[s * plane_px + at] : 1.0f;
+                    vw.depth[s * plane_px + at] = 1.0f;
                     if (vw.vis) vw.vis[s * plane_px + at] = RDR_PAIR_INVALID;
                 }
             }
@@ -551,16 +554,16 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
         return;
     }
 
-    uint32_t zi[Q][S];  // bits of the initial depth
+    // bits of the initial depth; the 4x view always starts from a clear (nothing to keep in registers)
+    constexpr uint32_t ONE = 0x3F800000u;
+    uint32_t zi1[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int pix = q * T + tid, px = ox0 + (pix & 15), py = oy0 + (pix >> 4);
         const bool in_view = px < (int)vw.w && py < (int)vw.h;
+        zi1[q] = (S == 1 && vw.load && in_view) ? __float_as_uint(vw.init[(size_t)py * vw.pitch + px]) : ONE;
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            zi[q][s] = __float_as_uint((vw.load && in_view) ? vw.init[s * plane_px + (size_t)py * vw.pitch + px] : 1.0f);
-            lds_key[s * 256 + pix] = (unsigned long long)zi[q][s] << 32;
-        }
+        for (int s = 0; s < S; s++) lds_key[s * 256 + pix] = (unsigned long long)(S == 1 ? zi1[q] : ONE) << 32;
     }
     const int sxo[4] = {96, 224, 32, 160}, syo[4] = {32, 96, 160, 224};
     // Smallest upper depth bound of the polygons seen so far that contain the whole tile (kept by wave 0). A record
@@ -577,15 +580,18 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
     // 32-bit multiply-adds, with the same sign as the 64-bit expression. Everything else (clipped polygons, very long
     // edges) keeps the 64-bit path; a polygon containing the whole tile needs no test at all.
     for (uint32_t base = begin; base < end; base += RASTER_CHUNK) {
+#ifdef RDR_RASTER_DIAG
+        if (RDR_RASTER_DIAG & 256) break;
+#endif
         const uint32_t cnt = min((uint32_t)RASTER_CHUNK, end - base);
         __syncthreads();  // the previous chunk's items are done with lds_rec (first pass: the keys are initialised)
         if ((uint32_t)tid < cnt) lds_ids[tid] = next_id;
         __syncthreads();
-        // the ids of the chunk after this one: in flight while this one is staged and rasterised
+        // eight consecutive threads copy one 128-byte record, 16 bytes each
+        for (uint32_t q = threadIdx.x; q < cnt * 8u; q += (uint32_t)T)
+            ((uint4*)lds_rec)[q] = ((const uint4*)(recs + lds_ids[q >> 3]))[q & 7u];
+        // the ids of the chunk after this one: in flight while this one is set up and rasterised
         if (tid < RASTER_CHUNK && base + RASTER_CHUNK + (uint32_t)tid < end) next_id = sorted_vals[base + RASTER_CHUNK + tid];
-        // 32 consecutive threads copy one 128-byte record
-        for (uint32_t dw = threadIdx.x; dw < cnt * 32u; dw += (uint32_t)T)
-            lds_rec[dw] = ((const uint32_t*)(recs + lds_ids[dw >> 5]))[dw & 31u];
         __syncthreads();
         // wave 0: area of each record's pixel box inside the tile, inclusive prefix sum over its lanes
         if (tid < 64) {
@@ -623,6 +629,11 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
             for (int d = 32; d >= 1; d >>= 1) chunk_far = fminf(chunk_far, __shfl_xor(chunk_far, d));
             tile_far = fminf(tile_far, chunk_far);
             if (z_lo > tile_far) { area = 0; cover = false; }
+#if defined(RDR_RASTER_DIAG)
+            if ((RDR_RASTER_DIAG & 16) && area >= 128u) { area = 0; cover = false; }
+            if ((RDR_RASTER_DIAG & 32) && area < 128u) { area = 0; cover = false; }
+            if ((RDR_RASTER_DIAG & 64) && cover) { area = 0; cover = false; }
+#endif
             uint32_t mode = cover ? RASTER_COVER : RASTER_EXACT64;
             if (area && !cover) mode = raster_localise<S>(lds_rec + tid * 32, ox0, oy0);
             if ((uint32_t)tid < cnt) lds_cover[tid] = mode;
@@ -636,7 +647,10 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
             if (tid == 0) lds_prefix[0] = 0u;
         }
         __syncthreads();
-        const uint32_t total = lds_prefix[RASTER_CHUNK];
+#ifndef RDR_RASTER_DIAG
+#define RDR_RASTER_DIAG 0  // timing experiments only (wrong pictures): 1 no atomics, 2 no depth, 4 no edge tests, 8 no items
+#endif
+        const uint32_t total = (RDR_RASTER_DIAG & 8) ? 0u : lds_prefix[RASTER_CHUNK];
         for (uint32_t wi = (uint32_t)tid; wi < total; wi += (uint32_t)T) {
             // largest lo with prefix[lo] <= wi; entries past the last record hold the total, which is > wi
             uint32_t lo = 0;
@@ -650,6 +664,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
             uint32_t rid;
             if (mode == RASTER_LOCAL32) {
                 const RasterLocal* f = (const RasterLocal*)(lds_rec + lo * 32);
+                if (RDR_RASTER_DIAG & 4) { x = ox0 + (int)(local & 15u); y = oy0 + (int)(local >> 4 & 15u); dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id; } else {
                 const uint32_t box = f->box;
                 const uint32_t bw = ((box >> 8) & 15u) + 1u;
                 const uint32_t row = __umul24(local, box >> 12) >> 16;   // local / bw, exact for local < 256
@@ -668,6 +683,7 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
                     inside &= ~outside;
                 }
                 dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id;
+                }
             } else {
                 const DTriRec* r = (const DTriRec*)(lds_rec + lo * 32);
                 const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1);
@@ -699,9 +715,10 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
                 for (int s = 0; s < S; s++) {
                     if (!(inside & (1u << s))) continue;
                     const int Px = Px0 + (S == 1 ? 128 : sxo[s]), Py = Py0 + (S == 1 ? 128 : syo[s]);
-                    float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
+                    float zz = (RDR_RASTER_DIAG & 2) ? (float)z00 + 1e-9f * (float)(Px + Py) : (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
                     zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
-                    atomicMin(&lds_key[s * 256 + pix], ((unsigned long long)__float_as_uint(zz) << 32) | rid);
+                    if (RDR_RASTER_DIAG & 1) { if (zz == 0.123f) lds_key[s * 256 + pix] = rid; }
+                    else atomicMin(&lds_key[s * 256 + pix], ((unsigned long long)__float_as_uint(zz) << 32) | rid);
                 }
             }
         }
@@ -712,21 +729,16 @@ __global__ void __launch_bounds__(T) k_raster(const DView* __restrict__ views, u
         const int pix = q * T + tid, px = ox0 + (pix & 15), py = oy0 + (pix >> 4);
         if (!(px < (int)vw.w && py < (int)vw.h)) continue;
         const size_t o = (size_t)py * vw.pitch + px;
-        bool changed = false;
         unsigned long long key[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            key[s] = lds_key[s * 256 + pix];
-            changed = changed || key[s] != ((unsigned long long)zi[q][s] << 32);
-        }
-        if (!vw.load || carry || changed) {
+        for (int s = 0; s < S; s++) key[s] = lds_key[s * 256 + pix];
+        // every pixel is stored, changed or not: whole sectors go out, none has to be merged in memory
 #pragma unroll
-            for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
-        }
+        for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
         if (vw.vis) {
 #pragma unroll
             for (int s = 0; s < S; s++)
-                vw.vis[s * plane_px + o] = key[s] != ((unsigned long long)zi[q][s] << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
+                vw.vis[s * plane_px + o] = key[s] != ((unsigned long long)(S == 1 ? zi1[q] : ONE) << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
         }
     }
 }
@@ -753,12 +765,31 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32
     if (!n_pairs) return;
     hipLaunchKernelGGL(k_ranges, dim3((n_pairs + 255) / 256), dim3(256), 0, s, keys, n_pairs, tile_ranges, tile_ranges + n_tiles);
 }
-void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange s1, RasterRange s4) {
-    if (s1.first_tile < s1.end_tile)
-        hipLaunchKernelGGL((k_raster<1, RDR_RASTER_T1, RDR_RASTER_C1>), dim3(s1.end_tile - s1.first_tile), dim3(RDR_RASTER_T1), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
-                           s1.first_view, s1.first_tile);
-    if (s4.first_tile < s4.end_tile)
-        hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4>), dim3(s4.end_tile - s4.first_tile), dim3(RDR_RASTER_T4), 0, s, views, n_views, recs, sorted_vals, tile_start, tile_end,
-                           s4.first_view, s4.first_tile);
+// Rasterises the tiles [r.first_tile, r.end_tile): the views from r.first_view on that have the sample count
+// `samples`, RDR_RASTER_MAX_VIEWS of them per launch. `views` is the host copy of the batch's view table, `d_views` the
+// device copy (single-sampled targets are first brought to their initial state from it, k_view_init).
+void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DView* d_views, const DTriRec* recs, const uint32_t* sorted_vals,
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples) {
+    if (r.first_tile >= r.end_tile) return;
+    uint32_t last = r.first_view;
+    while (last + 1 < n_views && views[last + 1].tile_base < r.end_tile) last++;
+    if (samples == 1) {
+        uint32_t mw = 0, mh = 0;
+        for (uint32_t v = r.first_view; v <= last; v++)
+            if (views[v].load == 1u && views[v].init != views[v].depth) { mw = max(mw, views[v].w); mh = max(mh, views[v].h); }
+        if (mw) hipLaunchKernelGGL(k_view_init, dim3((mw + 255u) / 256u, mh, last - r.first_view + 1u), dim3(256), 0, s, d_views, r.first_view);
+    }
+    for (uint32_t v0 = r.first_view; v0 <= last; v0 += RDR_RASTER_MAX_VIEWS) {
+        RasterViews tbl;
+        tbl.n = min((uint32_t)RDR_RASTER_MAX_VIEWS, last - v0 + 1u);
+        for (uint32_t k = 0; k < tbl.n; k++) { tbl.v[k] = views[v0 + k]; tbl.base[k] = views[v0 + k].tile_base; }
+        for (uint32_t k = tbl.n; k < RDR_RASTER_MAX_VIEWS; k++) tbl.base[k] = 0xFFFFFFFFu;
+        tbl.first_tile = tbl.base[0];
+        const DView& lv = tbl.v[tbl.n - 1];
+        const uint32_t n_tiles = lv.tile_base + lv.tiles_x * lv.tiles_y - tbl.first_tile;
+        if (samples == 1)
+            hipLaunchKernelGGL((k_raster<1, RDR_RASTER_T1, RDR_RASTER_C1>), dim3(n_tiles), dim3(RDR_RASTER_T1), 0, s, tbl, recs, sorted_vals, tile_start, tile_end);
+        else
+            hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4>), dim3(n_tiles), dim3(RDR_RASTER_T4), 0, s, tbl, recs, sorted_vals, tile_start, tile_end);
+    }
 }

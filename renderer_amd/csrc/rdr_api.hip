@@ -810,10 +810,13 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
     HIP_TRY(hipEventRecord(c->ev[8], c->stream));
     const RasterRange none = {0xFFFFFFFFu, 0u, 0u};
     auto launch = [&](hipStream_t st, const RasterRange& s1, const RasterRange& s4) {
-        launch_raster(st, c->d_views.as<DView>(), (uint32_t)b.views.size(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s1, s4);
+        launch_raster(st, b.views.data(), (uint32_t)b.views.size(), c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s1, 1);
+        launch_raster(st, b.views.data(), (uint32_t)b.views.size(), c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s4, 4);
     };
-    const bool side = rr[2].first_tile < rr[2].end_tile && (rr[0].first_tile < rr[0].end_tile || rr[1].first_tile < rr[1].end_tile);
+    // RDR_SERIAL_RASTER: measurement aid, the rasterisers one after the other so that a profile shows each alone
+    const bool side = rr[2].first_tile < rr[2].end_tile && (rr[0].first_tile < rr[0].end_tile || rr[1].first_tile < rr[1].end_tile) && !getenv("RDR_SERIAL_RASTER");
     if (side) {
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
