@@ -50,7 +50,7 @@ struct RasterRange { uint32_t first_tile, end_tile, first_view; };
 // the views of one rasteriser launch, passed by value in the kernel arguments
 #define RDR_RASTER_MAX_VIEWS 32
 struct RasterViews {
-    uint32_t n, first_tile;
+    uint32_t n, first_tile, end_tile, _pad;
     uint32_t base[RDR_RASTER_MAX_VIEWS];  // first tile of view k (0xFFFFFFFF past the last)
     DView v[RDR_RASTER_MAX_VIEWS];
 };

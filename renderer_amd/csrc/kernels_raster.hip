@@ -477,6 +477,13 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 #ifndef RDR_RASTER_C4
 #define RDR_RASTER_C4 32
 #endif
+// consecutive tiles per block
+#ifndef RDR_RASTER_K1
+#define RDR_RASTER_K1 1
+#endif
+#ifndef RDR_RASTER_K4
+#define RDR_RASTER_K4 1
+#endif
 
 // One block of T threads per 16x16 tile, staging the tile's triangle records C at a time. A tile spends most of its
 // life waiting for two dependent rounds of loads per chunk (the sorted triangle ids, then the records they point at;
@@ -510,7 +517,7 @@ __global__ void __launch_bounds__(256) k_view_init(const DView* __restrict__ vie
     vw.depth[at] = vw.init[at];
 }
 
-template <int S, int T, int RASTER_CHUNK>
+template <int S, int T, int RASTER_CHUNK, int TILES>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_raster(const RasterViews tbl, const DTriRec* __restrict__ recs, const uint32_t* __restrict__ sorted_vals,
                                               const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_end) {
     constexpr int Q = 256 / T;  // pixels of the tile per thread: pixel q*T + tid
@@ -520,25 +527,35 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
     __shared__ uint32_t lds_prefix[RASTER_CHUNK + 1];
     __shared__ uint32_t lds_cover[RASTER_CHUNK];     // RASTER_EXACT64 / RASTER_COVER / RASTER_LOCAL32, see below
     __shared__ unsigned long long lds_key[S * 256];  // [sample][pixel of the tile, row-major]
-    const uint32_t tile = tbl.first_tile + blockIdx.x;
     // A tile's life is a chain of dependent loads, and what a CU gets done is set by the length of that chain. The
-    // views of the launch travel in the kernel arguments (constant memory, no round trip to HBM), and the first
-    // triangle ids are fetched as soon as the list bounds are known.
-    const uint32_t begin = tile_start[tile], end = tile_end[tile];
-    uint32_t next_id = 0u;  // triangle id this thread stages for the coming chunk
-    if (threadIdx.x < (uint32_t)RASTER_CHUNK && begin + threadIdx.x < end) next_id = sorted_vals[begin + threadIdx.x];
+    // views of the launch travel in the kernel arguments (constant memory, no round trip to HBM). A block takes
+    // TILES consecutive tiles, one after the other: the list bounds of the next tile are fetched while this one is
+    // worked on, and its first triangle ids while this one's last chunk is rasterised, so that only the first tile of
+    // a block waits for them.
+    const int tid = (int)threadIdx.x;
+    const uint32_t tile0 = tbl.first_tile + blockIdx.x * (uint32_t)TILES;
+    uint32_t nbegin = tile_start[tile0], nend = tile_end[tile0];
+    uint32_t next_id = 0u;   // triangle id this thread stages for the coming chunk
+    bool have_ids = false;   // ... already fetched for the tile about to start
+    for (int t = 0; t < TILES; t++) {
+    const uint32_t tile = tile0 + (uint32_t)t;
+    if (tile >= tbl.end_tile) break;
+    const uint32_t begin = nbegin, end = nend;
+    nbegin = nend = 0u;
+    if (t + 1 < TILES && tile + 1u < tbl.end_tile) { nbegin = tile_start[tile + 1u]; nend = tile_end[tile + 1u]; }
+    if (!have_ids && tid < RASTER_CHUNK && begin + (uint32_t)tid < end) next_id = sorted_vals[begin + tid];
+    have_ids = false;
     // view of this tile: the last one whose first tile is <= tile (views are laid out in order of their tiles)
     uint32_t v = 0;
     for (uint32_t k = 1; k < tbl.n; k++) if (tbl.base[k] <= tile) v = k;
     v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     const DView vw = tbl.v[v];
     const uint32_t local_tile = tile - vw.tile_base;
-    if (local_tile >= vw.tiles_x * vw.tiles_y) return;
+    if (local_tile >= vw.tiles_x * vw.tiles_y) continue;
     const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
-    const int tid = (int)threadIdx.x;
     const size_t plane_px = (size_t)vw.pitch * vw.h;
     if (begin >= end) {                   // nothing drawn here: the tile is just cleared ...
-        if (S == 1 && vw.load) return;    // ... or, for a view that adds to what its target holds, left as it is
+        if (S == 1 && vw.load) continue;  // ... or, for a view that adds to what its target holds, left as it is
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int pix = q * T + tid, cx = ox0 + (pix & 15), cy = oy0 + (pix >> 4);
@@ -551,7 +568,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
                 }
             }
         }
-        return;
+        continue;
     }
 
     // bits of the initial depth; the 4x view always starts from a clear (nothing to keep in registers)
@@ -580,9 +597,6 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
     // 32-bit multiply-adds, with the same sign as the 64-bit expression. Everything else (clipped polygons, very long
     // edges) keeps the 64-bit path; a polygon containing the whole tile needs no test at all.
     for (uint32_t base = begin; base < end; base += RASTER_CHUNK) {
-#ifdef RDR_RASTER_DIAG
-        if (RDR_RASTER_DIAG & 256) break;
-#endif
         const uint32_t cnt = min((uint32_t)RASTER_CHUNK, end - base);
         __syncthreads();  // the previous chunk's items are done with lds_rec (first pass: the keys are initialised)
         if ((uint32_t)tid < cnt) lds_ids[tid] = next_id;
@@ -590,8 +604,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
         // eight consecutive threads copy one 128-byte record, 16 bytes each
         for (uint32_t q = threadIdx.x; q < cnt * 8u; q += (uint32_t)T)
             ((uint4*)lds_rec)[q] = ((const uint4*)(recs + lds_ids[q >> 3]))[q & 7u];
-        // the ids of the chunk after this one: in flight while this one is set up and rasterised
-        if (tid < RASTER_CHUNK && base + RASTER_CHUNK + (uint32_t)tid < end) next_id = sorted_vals[base + RASTER_CHUNK + tid];
+        // the ids of the chunk after this one - or of the next tile's first chunk: in flight while this one is set up
+        // and rasterised
+        if (base + RASTER_CHUNK < end) {
+            if (tid < RASTER_CHUNK && base + RASTER_CHUNK + (uint32_t)tid < end) next_id = sorted_vals[base + RASTER_CHUNK + tid];
+        } else if (nbegin < nend) {
+            if (tid < RASTER_CHUNK && nbegin + (uint32_t)tid < nend) next_id = sorted_vals[nbegin + tid];
+            have_ids = true;
+        }
         __syncthreads();
         // wave 0: area of each record's pixel box inside the tile, inclusive prefix sum over its lanes
         if (tid < 64) {
@@ -629,11 +649,6 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
             for (int d = 32; d >= 1; d >>= 1) chunk_far = fminf(chunk_far, __shfl_xor(chunk_far, d));
             tile_far = fminf(tile_far, chunk_far);
             if (z_lo > tile_far) { area = 0; cover = false; }
-#if defined(RDR_RASTER_DIAG)
-            if ((RDR_RASTER_DIAG & 16) && area >= 128u) { area = 0; cover = false; }
-            if ((RDR_RASTER_DIAG & 32) && area < 128u) { area = 0; cover = false; }
-            if ((RDR_RASTER_DIAG & 64) && cover) { area = 0; cover = false; }
-#endif
             uint32_t mode = cover ? RASTER_COVER : RASTER_EXACT64;
             if (area && !cover) mode = raster_localise<S>(lds_rec + tid * 32, ox0, oy0);
             if ((uint32_t)tid < cnt) lds_cover[tid] = mode;
@@ -647,10 +662,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
             if (tid == 0) lds_prefix[0] = 0u;
         }
         __syncthreads();
-#ifndef RDR_RASTER_DIAG
-#define RDR_RASTER_DIAG 0  // timing experiments only (wrong pictures): 1 no atomics, 2 no depth, 4 no edge tests, 8 no items
-#endif
-        const uint32_t total = (RDR_RASTER_DIAG & 8) ? 0u : lds_prefix[RASTER_CHUNK];
+        const uint32_t total = lds_prefix[RASTER_CHUNK];
         for (uint32_t wi = (uint32_t)tid; wi < total; wi += (uint32_t)T) {
             // largest lo with prefix[lo] <= wi; entries past the last record hold the total, which is > wi
             uint32_t lo = 0;
@@ -664,7 +676,6 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
             uint32_t rid;
             if (mode == RASTER_LOCAL32) {
                 const RasterLocal* f = (const RasterLocal*)(lds_rec + lo * 32);
-                if (RDR_RASTER_DIAG & 4) { x = ox0 + (int)(local & 15u); y = oy0 + (int)(local >> 4 & 15u); dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id; } else {
                 const uint32_t box = f->box;
                 const uint32_t bw = ((box >> 8) & 15u) + 1u;
                 const uint32_t row = __umul24(local, box >> 12) >> 16;   // local / bw, exact for local < 256
@@ -683,7 +694,6 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
                     inside &= ~outside;
                 }
                 dzdX = f->dzdX; dzdY = f->dzdY; z00 = f->z00; rid = f->id;
-                }
             } else {
                 const DTriRec* r = (const DTriRec*)(lds_rec + lo * 32);
                 const int bx0 = max((int)r->px0, ox0), bx1 = min((int)r->px1, ox0 + RDR_TILE - 1);
@@ -715,10 +725,9 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
                 for (int s = 0; s < S; s++) {
                     if (!(inside & (1u << s))) continue;
                     const int Px = Px0 + (S == 1 ? 128 : sxo[s]), Py = Py0 + (S == 1 ? 128 : syo[s]);
-                    float zz = (RDR_RASTER_DIAG & 2) ? (float)z00 + 1e-9f * (float)(Px + Py) : (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
+                    float zz = (float)fma(dzdX, (double)Px, fma(dzdY, (double)Py, z00));
                     zz = zz < 0.0f ? 0.0f : (zz > 1.0f ? 1.0f : zz);
-                    if (RDR_RASTER_DIAG & 1) { if (zz == 0.123f) lds_key[s * 256 + pix] = rid; }
-                    else atomicMin(&lds_key[s * 256 + pix], ((unsigned long long)__float_as_uint(zz) << 32) | rid);
+                    atomicMin(&lds_key[s * 256 + pix], ((unsigned long long)__float_as_uint(zz) << 32) | rid);
                 }
             }
         }
@@ -741,6 +750,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
                 vw.vis[s * plane_px + o] = key[s] != ((unsigned long long)(S == 1 ? zi1[q] : ONE) << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
         }
     }
+    }  // tiles of the block
 }
 
 }  // namespace
@@ -786,10 +796,13 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DV
         for (uint32_t k = tbl.n; k < RDR_RASTER_MAX_VIEWS; k++) tbl.base[k] = 0xFFFFFFFFu;
         tbl.first_tile = tbl.base[0];
         const DView& lv = tbl.v[tbl.n - 1];
-        const uint32_t n_tiles = lv.tile_base + lv.tiles_x * lv.tiles_y - tbl.first_tile;
+        tbl.end_tile = lv.tile_base + lv.tiles_x * lv.tiles_y;
+        const uint32_t n_tiles = tbl.end_tile - tbl.first_tile;
         if (samples == 1)
-            hipLaunchKernelGGL((k_raster<1, RDR_RASTER_T1, RDR_RASTER_C1>), dim3(n_tiles), dim3(RDR_RASTER_T1), 0, s, tbl, recs, sorted_vals, tile_start, tile_end);
+            hipLaunchKernelGGL((k_raster<1, RDR_RASTER_T1, RDR_RASTER_C1, RDR_RASTER_K1>), dim3((n_tiles + RDR_RASTER_K1 - 1) / RDR_RASTER_K1), dim3(RDR_RASTER_T1), 0, s,
+                               tbl, recs, sorted_vals, tile_start, tile_end);
         else
-            hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4>), dim3(n_tiles), dim3(RDR_RASTER_T4), 0, s, tbl, recs, sorted_vals, tile_start, tile_end);
+            hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4, RDR_RASTER_K4>), dim3((n_tiles + RDR_RASTER_K4 - 1) / RDR_RASTER_K4), dim3(RDR_RASTER_T4), 0, s,
+                               tbl, recs, sorted_vals, tile_start, tile_end);
     }
 }

@@ -149,8 +149,9 @@ RDR_DEV void shade_sky(const DFrame& fr, int px, int py, float out[4]) {
     if (fr.env.res) cube_sample_fast(fr.env, 0, d.x, d.y, d.z, e);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
+        // v in [0, 1): the hardware log2 / exp2 are as good as the library's pow here (the result is stored as half)
         const float v = e[k] / (e[k] + 1.0f);
-        out[k] = __powf(v, 1.0f / 2.2f);
+        out[k] = v > 0.0f ? __builtin_amdgcn_exp2f((1.0f / 2.2f) * __builtin_amdgcn_logf(v)) : 0.0f;
     }
     out[3] = 1.0f;
 }

@@ -763,22 +763,6 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     uint32_t* vals[2] = {c->d_vals[0].as<uint32_t>(), c->d_vals[1].as<uint32_t>()};
     const int cur = launch_radix_sort(c->stream, keys, vals, n_pairs, key_bits, c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(), counters + 2);
     launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), n_tiles);
-    if (getenv("RDR_DEBUG_TILE_LISTS")) {  // diagnostic: list length per tile, per view
-        std::vector<uint32_t> tr((size_t)n_tiles * 2);
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipMemcpy(tr.data(), c->d_tile_start.p, tr.size() * 4, hipMemcpyDeviceToHost);
-        for (const DView& v : b.views) {
-            const uint32_t nt = v.tiles_x * v.tiles_y;
-            uint64_t sum = 0; uint32_t mx = 0, nonempty = 0, over[4] = {0, 0, 0, 0};
-            for (uint32_t t = v.tile_base; t < v.tile_base + nt; t++) {
-                const uint32_t len = tr[n_tiles + t] - tr[t];
-                sum += len; mx = std::max(mx, len); nonempty += len > 0;
-                over[0] += len > 64; over[1] += len > 256; over[2] += len > 1024; over[3] += len > 4096;
-            }
-            fprintf(stderr, "view %ux%u s%u load %u: tiles %u nonempty %u pairs %llu max %u  >64:%u >256:%u >1024:%u >4096:%u\n", v.w, v.h, v.samples,
-                    v.load, nt, nonempty, (unsigned long long)sum, mx, over[0], over[1], over[2], over[3]);
-        }
-    }
     c->stats.triangle_instances += n_inst;
     c->stats.tile_pairs += n_pairs;
     c->stats.views += (uint32_t)b.views.size() - b.views_dropped;
