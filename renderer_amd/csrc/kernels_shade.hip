@@ -212,9 +212,13 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
 // pbr.frag at the centre of pixel (px,py) of the triangle whose vertex-stage outputs are in T.
 // MASKED = false for the opaque list, which holds no alpha-masked primitive: the cut-off test and its early
 // exit disappear and the five texture fetches can be in flight together.
+// `park`: null, or this thread's column of a [12][256] float array in LDS. The world position and the three
+// interpolated frame vectors are not needed while the textures are fetched and filtered - the part of the function
+// that takes every register there is - and wait there meanwhile (otherwise the compiler spills them, and more, to
+// scratch memory: stores that go out to HBM).
 template <bool MASKED>
 RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ lights, const float* srgb, const DShadeTri& T, int px, int py,
-                            float out[4]) {
+                            float out[4], float* park = nullptr) {
     // Multiply-add pairs may fuse in this function: what must round as in the CPU checker is written with explicit
     // fma / fmaf calls or sits in the cascade block below, which switches fusing off again.
 #pragma clang fp contract(fast)
@@ -241,13 +245,20 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
 #pragma unroll
         for (int k = 0; k < 3; k++) { lam[1][k] = lx[k] * ix; lam[2][k] = ly[k] * iy; }
     }
-    const F3 P = f3(interp3(lam[0], T.wp[0], T.wp[1], T.wp[2]), interp3(lam[0], T.wp[3], T.wp[4], T.wp[5]), interp3(lam[0], T.wp[6], T.wp[7], T.wp[8]));
-    const F3 Nv = f3(interp3(lam[0], T.nrm[0], T.nrm[1], T.nrm[2]), interp3(lam[0], T.nrm[3], T.nrm[4], T.nrm[5]), interp3(lam[0], T.nrm[6], T.nrm[7], T.nrm[8]));
-    const F3 Tv = f3(interp3(lam[0], T.tan[0], T.tan[1], T.tan[2]), interp3(lam[0], T.tan[3], T.tan[4], T.tan[5]), interp3(lam[0], T.tan[6], T.tan[7], T.tan[8]));
-    const F3 Bv = f3(interp3(lam[0], T.bit[0], T.bit[1], T.bit[2]), interp3(lam[0], T.bit[3], T.bit[4], T.bit[5]), interp3(lam[0], T.bit[6], T.bit[7], T.bit[8]));
+    F3 P = f3(interp3(lam[0], T.wp[0], T.wp[1], T.wp[2]), interp3(lam[0], T.wp[3], T.wp[4], T.wp[5]), interp3(lam[0], T.wp[6], T.wp[7], T.wp[8]));
+    F3 Nv = f3(interp3(lam[0], T.nrm[0], T.nrm[1], T.nrm[2]), interp3(lam[0], T.nrm[3], T.nrm[4], T.nrm[5]), interp3(lam[0], T.nrm[6], T.nrm[7], T.nrm[8]));
+    F3 Tv = f3(interp3(lam[0], T.tan[0], T.tan[1], T.tan[2]), interp3(lam[0], T.tan[3], T.tan[4], T.tan[5]), interp3(lam[0], T.tan[6], T.tan[7], T.tan[8]));
+    F3 Bv = f3(interp3(lam[0], T.bit[0], T.bit[1], T.bit[2]), interp3(lam[0], T.bit[3], T.bit[4], T.bit[5]), interp3(lam[0], T.bit[6], T.bit[7], T.bit[8]));
     const float u0 = interp3(lam[0], T.uv[0], T.uv[1], T.uv[2]), v0 = interp3(lam[0], T.uv[3], T.uv[4], T.uv[5]);
     const float dudx = interp3(lam[1], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdx = interp3(lam[1], T.uv[3], T.uv[4], T.uv[5]) - v0;
     const float dudy = interp3(lam[2], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdy = interp3(lam[2], T.uv[3], T.uv[4], T.uv[5]) - v0;
+    if (park) {
+        park[0 * 256] = P.x; park[1 * 256] = P.y; park[2 * 256] = P.z;
+        park[3 * 256] = Nv.x; park[4 * 256] = Nv.y; park[5 * 256] = Nv.z;
+        park[6 * 256] = Tv.x; park[7 * 256] = Tv.y; park[8 * 256] = Tv.z;
+        park[9 * 256] = Bv.x; park[10 * 256] = Bv.y; park[11 * 256] = Bv.z;
+        __asm__ volatile("" ::: "memory");  // the values are read back below, not kept
+    }
     __builtin_amdgcn_sched_barrier(0);  // the loads below stay below: the record is consumed in stages, not held whole
     const DShadeTri& mt = T;  // material block and texture descriptors travel with the triangle
 
@@ -337,6 +348,13 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
 #undef RDR_SAMPLE_SLOT
         }
     } else if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    if (park) {
+        __asm__ volatile("" ::: "memory");
+        P = f3(park[0 * 256], park[1 * 256], park[2 * 256]);
+        Nv = f3(park[3 * 256], park[4 * 256], park[5 * 256]);
+        Tv = f3(park[6 * 256], park[7 * 256], park[8 * 256]);
+        Bv = f3(park[9 * 256], park[10 * 256], park[11 * 256]);
+    }
     const F3 Tn = fast_normalize(Tv), Bn = fast_normalize(Bv), Nn = fast_normalize(Nv);
     const float nx = nmap[0] * 2.0f - 1.0f, ny = nmap[1] * 2.0f - 1.0f, nz = nmap[2] * 2.0f - 1.0f;
     const F3 N = fast_normalize(Tn * nx + Bn * ny + Nn * nz);
@@ -513,6 +531,52 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 // and to a multiple of 8 squares; blocks of tiles outside the screen return at once.
 #define RDR_SHADE_SQ_LOG2 3u
 
+// The tail of k_shade_opaque for one pixel, from what the block left in LDS: fed from LDS, the block's tile and the
+// thread index only, so that nothing of it is alive during the fragment loop.
+template <int S>
+RDR_DEV void resolve_pixel(const DFrame& fr, uint32_t state, const uint2* lds_frag_col, int tx, int ty, uint2* __restrict__ hdr,
+                                                     uint2* __restrict__ samples_out, const uint32_t* __restrict__ blend_start,
+                                                     const uint32_t* __restrict__ blend_end) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
+    if (!(px < (int)fr.W && py < (int)fr.H)) return;
+    const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
+    const uint32_t tile = (uint32_t)ty * ((fr.W + RDR_TILE - 1) / RDR_TILE) + (uint32_t)tx;
+    const uint32_t before = state & 0xFFFFu;
+    uint32_t slot[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) { slot[s] = (state >> (16 + 4 * s)) & 15u; if (slot[s] == 15u) slot[s] = SHADE_NO_FRAGMENT; }
+    bool any_sky = false;
+#pragma unroll
+    for (int s = 0; s < S; s++) any_sky = any_sky || slot[s] == SHADE_NO_FRAGMENT;
+    uint2 sky_packed = make_uint2(0u, 0u);
+    if (any_sky) {
+        float sky[4];
+        shade_sky(fr, px, py, sky);
+        sky_packed = pack_half4(sky[0], sky[1], sky[2], sky[3]);
+    }
+    uint2 sc[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) sc[s] = slot[s] == SHADE_NO_FRAGMENT ? sky_packed : lds_frag_col[before + slot[s]];
+    const bool keep_samples = S > 1 && samples_out && blend_start[tile] < blend_end[tile];
+    if (S == 1) {
+        hdr[o] = sc[0];
+    } else if (keep_samples) {
+#pragma unroll
+        for (int s = 0; s < S; s++) samples_out[s * plane_px + o] = sc[s];
+    } else {
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            float c[4];
+            unpack_half4(sc[s], c[0], c[1], c[2], c[3]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) sum[k] += c[k];
+        }
+        hdr[o] = pack_half4(sum[0] * (1.0f / S), sum[1] * (1.0f / S), sum[2] * (1.0f / S), sum[3] * (1.0f / S));
+    }
+}
+
 // Opaque draws + skybox. S == 1: writes hdr. S == 4: resolves straight into
 // hdr, except in tiles whose blended-pass triangle list is not empty
 // (blend_start < blend_end): those keep their four sample colours in
@@ -532,6 +596,11 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
     __shared__ uint8_t lds_frag_px[256 * S];    // its pixel = the thread index that owns the pixel
     __shared__ uint2 lds_frag_col[256 * S];     // shaded colour, RGBA16F
     __shared__ uint32_t lds_wave_total[4];
+    // What a pixel needs again after the fragment loop - which fragment each of its samples resolves to - waits in LDS
+    // meanwhile: values that live in registers across the loop are spilled by the compiler (the loop body takes the whole
+    // register budget), and a spill is a store that goes all the way to HBM.
+    __shared__ uint32_t lds_pixel_state[256];   // first fragment of the pixel | slot of sample s << (16 + 4 s)
+    __shared__ float lds_park[12 * 256];        // see shade_fragment
     const DFrame& fr = *frp;
     lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
     const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
@@ -540,7 +609,6 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
     const uint32_t nth = blockIdx.x >> 3, sq = (nth >> (2u * Q)) * 8u + (blockIdx.x & 7u), in_sq = nth & (side * side - 1u), sq_x = (tiles_x + side - 1u) >> Q;
     const int tx = (int)((sq % sq_x) * side + (in_sq & (side - 1u))), ty = (int)((sq / sq_x) * side + (in_sq >> Q));
     if ((uint32_t)tx >= tiles_x || (uint32_t)ty * tiles_x + (uint32_t)tx >= n_tiles) return;
-    const uint32_t tile = (uint32_t)ty * tiles_x + (uint32_t)tx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool in_view = px < (int)fr.W && py < (int)fr.H;
@@ -583,6 +651,12 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
 #pragma unroll
     for (int k = 0; k < S; k++)
         if ((uint32_t)k < n_unique) { lds_frag_id[before + k] = ids[k]; lds_frag_px[before + k] = (uint8_t)threadIdx.x; }
+    {
+        uint32_t st = before;  // < 1024
+#pragma unroll
+        for (int s = 0; s < S; s++) st |= (slot[s] & 15u) << (16 + 4 * s);  // SHADE_NO_FRAGMENT -> 15
+        lds_pixel_state[threadIdx.x] = st;
+    }
     __syncthreads();
 
     // ---- shade the fragment list densely
@@ -591,42 +665,12 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
         const int fw = (int)(t >> 6), fl = (int)(t & 63u);
         const int fx = tx * RDR_TILE + (fw & 1) * 8 + (fl & 7), fy = ty * RDR_TILE + (fw >> 1) * 8 + (fl >> 3);
         float c[4];
-        shade_fragment<false>(fr, lights, lds_srgb, tris[id], fx, fy, c);
+        shade_fragment<false>(fr, lights, lds_srgb, tris[id], fx, fy, c, lds_park + threadIdx.x);
         lds_frag_col[f] = pack_half4(c[0], c[1], c[2], c[3]);
     }
     __syncthreads();
-    if (!in_view) return;
-
     // ---- per pixel: sky where needed, gather the sample colours, store or resolve
-    bool any_sky = false;
-#pragma unroll
-    for (int s = 0; s < S; s++) any_sky = any_sky || slot[s] == SHADE_NO_FRAGMENT;
-    uint2 sky_packed = make_uint2(0u, 0u);
-    if (any_sky) {
-        float sky[4];
-        shade_sky(fr, px, py, sky);
-        sky_packed = pack_half4(sky[0], sky[1], sky[2], sky[3]);
-    }
-    uint2 sc[S];
-#pragma unroll
-    for (int s = 0; s < S; s++) sc[s] = slot[s] == SHADE_NO_FRAGMENT ? sky_packed : lds_frag_col[before + slot[s]];
-    const bool keep_samples = S > 1 && samples_out && blend_start[tile] < blend_end[tile];
-    if (S == 1) {
-        hdr[o] = sc[0];
-    } else if (keep_samples) {
-#pragma unroll
-        for (int s = 0; s < S; s++) samples_out[s * plane_px + o] = sc[s];
-    } else {
-        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            float c[4];
-            unpack_half4(sc[s], c[0], c[1], c[2], c[3]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) sum[k] += c[k];
-        }
-        hdr[o] = pack_half4(sum[0] * (1.0f / S), sum[1] * (1.0f / S), sum[2] * (1.0f / S), sum[3] * (1.0f / S));
-    }
+    resolve_pixel<S>(fr, lds_pixel_state[threadIdx.x], lds_frag_col, tx, ty, hdr, samples_out, blend_start, blend_end);
 }
 
 #define BLEND_CHUNK 64
