@@ -212,13 +212,13 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
 // pbr.frag at the centre of pixel (px,py) of the triangle whose vertex-stage outputs are in T.
 // MASKED = false for the opaque list, which holds no alpha-masked primitive: the cut-off test and its early
 // exit disappear and the five texture fetches can be in flight together.
-// `park`: null, or this thread's column of a [12][256] float array in LDS. The world position and the three
+// `park` (PARK): this thread's column of a [12][256] float array in LDS. The world position and the three
 // interpolated frame vectors are not needed while the textures are fetched and filtered - the part of the function
 // that takes every register there is - and wait there meanwhile (otherwise the compiler spills them, and more, to
 // scratch memory: stores that go out to HBM).
-template <bool MASKED>
+template <bool MASKED, bool PARK>
 RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ lights, const float* srgb, const DShadeTri& T, int px, int py,
-                            float out[4], float* park = nullptr) {
+                            float out[4], float* park) {
     // Multiply-add pairs may fuse in this function: what must round as in the CPU checker is written with explicit
     // fma / fmaf calls or sits in the cascade block below, which switches fusing off again.
 #pragma clang fp contract(fast)
@@ -252,7 +252,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
     const float u0 = interp3(lam[0], T.uv[0], T.uv[1], T.uv[2]), v0 = interp3(lam[0], T.uv[3], T.uv[4], T.uv[5]);
     const float dudx = interp3(lam[1], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdx = interp3(lam[1], T.uv[3], T.uv[4], T.uv[5]) - v0;
     const float dudy = interp3(lam[2], T.uv[0], T.uv[1], T.uv[2]) - u0, dvdy = interp3(lam[2], T.uv[3], T.uv[4], T.uv[5]) - v0;
-    if (park) {
+    if (PARK) {
         park[0 * 256] = P.x; park[1 * 256] = P.y; park[2 * 256] = P.z;
         park[3 * 256] = Nv.x; park[4 * 256] = Nv.y; park[5 * 256] = Nv.z;
         park[6 * 256] = Tv.x; park[7 * 256] = Tv.y; park[8 * 256] = Tv.z;
@@ -348,7 +348,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
 #undef RDR_SAMPLE_SLOT
         }
     } else if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
-    if (park) {
+    if (PARK) {
         __asm__ volatile("" ::: "memory");
         P = f3(park[0 * 256], park[1 * 256], park[2 * 256]);
         Nv = f3(park[3 * 256], park[4 * 256], park[5 * 256]);
@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFr
         const int fw = (int)(t >> 6), fl = (int)(t & 63u);
         const int fx = tx * RDR_TILE + (fw & 1) * 8 + (fl & 7), fy = ty * RDR_TILE + (fw >> 1) * 8 + (fl >> 3);
         float c[4];
-        shade_fragment<false>(fr, lights, lds_srgb, tris[id], fx, fy, c, lds_park + threadIdx.x);
+        shade_fragment<false, true>(fr, lights, lds_srgb, tris[id], fx, fy, c, lds_park + threadIdx.x);
         lds_frag_col[f] = pack_half4(c[0], c[1], c[2], c[3]);
     }
     __syncthreads();
@@ -840,11 +840,12 @@ __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__
 }
 
 // One lane per fragment slot; the grid is fixed and strides over the slots in use.
-__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_blend_shade(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
+__global__ void __launch_bounds__(256, 4) k_blend_shade(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
                                                                       const DShadeTri* __restrict__ tris,
                                                                       const uint4* __restrict__ frags, float4* __restrict__ frag_col,
                                                                       const uint32_t* __restrict__ frag_used, uint32_t capacity) {
     __shared__ float lds_srgb[256];
+    __shared__ float lds_park[12 * 256];  // see shade_fragment
     const DFrame& fr = *frp;
     lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
     __syncthreads();
@@ -853,7 +854,7 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_blend_shade(const DFra
         const uint4 m = frags[f];
         if (m.x == BLEND_NONE) continue;
         float c[4];
-        shade_fragment<true>(fr, lights, lds_srgb, tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c);
+        shade_fragment<true, true>(fr, lights, lds_srgb, tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c, lds_park + threadIdx.x);
         frag_col[f] = make_float4(c[0], c[1], c[2], c[3]);
     }
 }
