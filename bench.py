@@ -27,11 +27,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak
 VALU_FP32_PEAK_TF = 157.3    # MI355X vector FP32 peak
-# Bytes the post chain has to move per pixel of the frame: first down-sample reads the colour image (8) and writes mip 1
-# (1); mip 1 -> 2 (1.25); the fused small levels down (0.33) and up (0.66); mip 2 -> 1 read-modify-write (2.25); the
-# tonemap pass reads colour (8) and mip 1 (1) and writes the frame (4). The reference's own passes, which also store bloom
-# mip 0 and the whole log-luminance image, move 50.65.
-POST_BYTES_PER_PX = 26.5
+# Algorithmic bytes of the post chain per pixel of the frame, by the reference's own pass structure and formats: copy of
+# the colour image into bloom mip 0 (12), five down-samples (6.66), five up-samples (11.99), tonemap (20).
+POST_BYTES_PER_PX = 50.65
+# Bytes the fused chain of this library has to move: first down-sample reads the colour image (8) and writes mip 1 (1);
+# mip 1 -> 2 (1.25); the fused small levels down (0.33) and up (0.66); mip 2 -> 1 read-modify-write (2.25); the tonemap
+# pass reads colour (8) and mip 1 (1) and writes the frame (4). Bloom mip 0 and the log-luminance image outside the
+# luminance window are not stored (nothing reads them).
+POST_BYTES_MOVED_PER_PX = 26.5
 
 
 def shade_flops_per_px(n_point_lights):
@@ -236,7 +239,9 @@ def main():
                          "algorithmic": f"{shade_flops_per_px(n_lights):.0f} flop/px x {n_px} px", "valu_measured": measured_valu("k_shade_opaque")},
             "roofline_passes": [
                 {"pass": "bloom chain + tonemap + luminance", "bound": "hbm", "achieved": post_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": post_gbs / HBM_PEAK_GBS, "ms": post_ms, "algorithmic": f"{POST_BYTES_PER_PX} B/px x {n_px} px"},
+                 "frac": post_gbs / HBM_PEAK_GBS, "ms": post_ms, "algorithmic": f"{POST_BYTES_PER_PX} B/px x {n_px} px",
+                 "moved": f"{POST_BYTES_MOVED_PER_PX} B/px by this library's fused passes",
+                 "frac_by_moved_bytes": post_gbs / HBM_PEAK_GBS * POST_BYTES_MOVED_PER_PX / POST_BYTES_PER_PX},
             ],
             "device_ms": {k: v / K for k, v in acc.items()},
             "frame_counters": {"triangle_instances": int(last_stats.triangle_instances), "triangles_binned": int(last_stats.triangles_binned),

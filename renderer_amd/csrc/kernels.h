@@ -60,8 +60,29 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DV
 // kernels_shade.hip
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,
                         const uint32_t* pair_offset, uint32_t n_after, const uint32_t* pair_total, DShadeTri* out);
-void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const float* depth, const uint32_t* vis,
-                         void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H);
+// opaque pass: fragment lists (one per screen rectangle), see kernels_shade.hip
+#define RDR_FRAG_SEGS 64u
+#define RDR_FRAG_CTR_STRIDE 32u  // words between two list counters (128 bytes)
+
+struct FragLists {
+    uint32_t rect_w, rect_h;  // rectangle size in tiles
+    uint32_t cap;             // slots per list
+    uint32_t* count;          // fill count of list s at count[s * RDR_FRAG_CTR_STRIDE]; list s = die * 8 + grid row
+    uint32_t* claim;          // chunks handed out of die d's lists at claim[d * RDR_FRAG_CTR_STRIDE]
+    uint2* recs;              // [RDR_FRAG_SEGS][cap]: triangle id, x | y << 16
+    uint2* cols;              // same layout: RGBA16F
+    uint32_t* pixel_state;    // [tile][256]: first fragment of the pixel, relative to the tile's | slot of sample s << (16 + 4 s)
+    uint32_t* tile_first;     // [tile]: position (in recs / cols) of the tile's first fragment
+};
+
+size_t shade_frag_slots(uint32_t W, uint32_t H, int samples);  // slots of recs / cols
+uint32_t shade_frags_blocks_per_cu();  // blocks of k_shade_frags that fit a compute unit
+FragLists make_frag_lists(uint32_t W, uint32_t H, int samples, void* frag_recs, void* frag_cols, uint32_t* pixel_state, uint32_t* tile_first,
+                          uint32_t* list_count, uint32_t* list_claim);
+void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const float* depth, const uint32_t* vis, const FragLists& L);
+void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks);
+void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const FragLists& L, void* hdr, void* samples_out, const uint32_t* blend_start,
+                         const uint32_t* blend_end, uint32_t W, uint32_t H);
 // blended pass: fragment list slots are handed out in runs of RDR_FRAG_RUN; `capacity` slots exist (see blend_capacity);
 // *frag_used counts the slots handed out and must be zero when launch_raster_blend is called
 #define RDR_FRAG_RUN 128u

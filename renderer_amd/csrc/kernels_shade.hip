@@ -524,40 +524,179 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 }
 
 #define SHADE_NO_FRAGMENT 0xFFu
-// Workgroups of a launch go to the 8 dies (XCDs, each with its own L2) round-robin by block index. The opaque pass
-// walks the screen in squares of 2^RDR_SHADE_SQ_LOG2 tiles a side and deals the squares to the dies in turn: the
-// blocks a die has in flight then lie next to each other on the screen and share shadow-map and texture lines in its
-// L2, while every die still gets an even mix of cheap (sky) and expensive regions. The grid is padded to whole squares
-// and to a multiple of 8 squares; blocks of tiles outside the screen return at once.
-#define RDR_SHADE_SQ_LOG2 3u
 
-// The tail of k_shade_opaque for one pixel, from what the block left in LDS: fed from LDS, the block's tile and the
-// thread index only, so that nothing of it is alive during the fragment loop.
+// ---- Opaque draws + skybox, in three kernels.
+//
+// With 4x MSAA a pixel is shaded once per DISTINCT triangle among its samples. A 16x16 tile of the benchmark frame
+// holds 288 such fragments on average and almost never exactly 256, so a block that shades "its" tile spends a second,
+// nearly empty pass on the overhang while three of its four waves wait at a barrier. The fragments of the whole frame
+// are therefore compacted into lists first and shaded from the lists, every wave full, no barrier anywhere:
+//
+//   k_frag_classify  one block per tile: the distinct triangles of every pixel's samples -> fragment records
+//                    (triangle, pixel) appended to the list of the tile's screen rectangle; per pixel a state word
+//                    (first fragment relative to the tile's, which fragment each sample resolves to); per tile the
+//                    position of its first fragment.
+//   k_shade_frags    a fixed grid of waves, each taking 64 consecutive fragments of a list at a time: pbr.frag per
+//                    fragment, colour stored as RGBA16F beside the record.
+//   k_frag_resolve   one lane per pixel: sky where a sample saw no triangle, sample colours from the fragment
+//                    colours, multisample resolve (or the four sample colours, in tiles the blended pass goes on with).
+//
+// The screen is cut into 8 x 8 rectangles, one list each (RDR_FRAG_SEGS lists at fixed positions of one buffer, each as
+// large as its rectangle can need, the fill counts a cache line apart: a single list would put one atomic per tile on
+// one address). The rectangle in column i, row j of that grid belongs to die (i + j) mod 8, so every die (XCD, with its
+// own L2) owns one rectangle of every row and every column of the grid: an even mix of sky and lit regions, and the
+// waves of a die, which take the chunks of its lists in order, work on neighbouring tiles at any one time and share
+// shadow-map and texture lines in that L2. Workgroups go to the dies round-robin by block index; a wave whose die has
+// run dry takes chunks from the next die's lists, so no die idles at the end. List order inside a rectangle is the
+// order in which its tiles' blocks arrive; colours do not depend on it.
 template <int S>
-RDR_DEV void resolve_pixel(const DFrame& fr, uint32_t state, const uint2* lds_frag_col, int tx, int ty, uint2* __restrict__ hdr,
-                                                     uint2* __restrict__ samples_out, const uint32_t* __restrict__ blend_start,
-                                                     const uint32_t* __restrict__ blend_end) {
+__global__ void __launch_bounds__(256) k_frag_classify(const DFrame* __restrict__ frp, const float* __restrict__ depth,
+                                                       const uint32_t* __restrict__ vis, FragLists L) {
+    __shared__ uint32_t lds_wave_total[4];
+    __shared__ uint32_t lds_base;
+    const DFrame& fr = *frp;
+    const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE, tiles_y = (fr.H + RDR_TILE - 1) / RDR_TILE;
+    // the 64 rectangles advance together, each through its tiles row by row
+    const uint32_t rect = blockIdx.x & 63u, in_rect = blockIdx.x >> 6;
+    const uint32_t gx = rect & 7u, gy = rect >> 3;
+    const uint32_t tx = gx * L.rect_w + in_rect % L.rect_w, ty = gy * L.rect_h + in_rect / L.rect_w;
+    if (tx >= tiles_x || ty >= tiles_y) return;
+    const uint32_t list = ((gx + gy) & 7u) * 8u + gy;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px = (int)tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = (int)ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool in_view = px < (int)fr.W && py < (int)fr.H;
+    const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
+
+    // ---- the samples of this pixel: sky, or the u-th distinct triangle of the pixel
+    uint32_t ids[S];
+    uint32_t slot[S];
+    uint32_t n_unique = 0;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        slot[s] = 15u;
+        if (!in_view) continue;
+        const uint32_t id = vis[s * plane_px + o];
+        const float zd = depth[s * plane_px + o];
+        if (id == 0xFFFFFFFFu || zd >= 1.0f) continue;
+        uint32_t u = n_unique;
+#pragma unroll
+        for (int k = S - 1; k >= 0; k--) if ((uint32_t)k < n_unique && ids[k] == id) u = (uint32_t)k;
+        if (u == n_unique) { ids[n_unique] = id; n_unique++; }
+        slot[s] = u;
+    }
+    // ---- exclusive prefix sum of n_unique (0..4) over the block: three ballots per wave, then the wave totals
+    uint32_t before = 0, wave_total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 3; bit++) {
+        const unsigned long long m = __ballot((n_unique >> bit) & 1u);
+        before += (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) << bit;
+        wave_total += (uint32_t)__popcll(m) << bit;
+    }
+    if (lane == 0) lds_wave_total[wave] = wave_total;
+    __syncthreads();
+    uint32_t n_frag = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) before += lds_wave_total[w];
+        n_frag += lds_wave_total[w];
+    }
+    const uint32_t tile = ty * tiles_x + tx;
+    if (threadIdx.x == 0) {
+        const uint32_t at = n_frag ? atomicAdd(L.count + list * RDR_FRAG_CTR_STRIDE, n_frag) : 0u;  // <= cap - n_frag: the list holds every sample of its rectangle
+        lds_base = list * L.cap + at;
+        L.tile_first[tile] = list * L.cap + at;
+    }
+    __syncthreads();
+    const uint32_t base = lds_base + before;
+    const uint32_t xy = (uint32_t)px | ((uint32_t)py << 16);
+#pragma unroll
+    for (int k = 0; k < S; k++)
+        if ((uint32_t)k < n_unique) L.recs[base + k] = make_uint2(ids[k], xy);
+    uint32_t st = before;  // < 1024
+#pragma unroll
+    for (int s = 0; s < S; s++) st |= slot[s] << (16 + 4 * s);
+    L.pixel_state[(size_t)tile * 256u + threadIdx.x] = st;
+}
+
+#ifndef RDR_SHADE_WAVES
+#define RDR_SHADE_WAVES 4  // waves per SIMD the register allocation is held to (128 VGPRs)
+#endif
+__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_frags(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
+                                                                      const DShadeTri* __restrict__ tris, FragLists L) {
+    __shared__ float lds_srgb[256];
+    __shared__ float lds_park[12 * 256];  // see shade_fragment
+    const DFrame& fr = *frp;
+    lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    // lane l looks after list l: its fill count, and where its 64-fragment chunks lie among those of its die's lists
+    const uint32_t cnt = L.count[lane * RDR_FRAG_CTR_STRIDE];
+    const uint32_t chunks = (cnt + 63u) >> 6;
+    uint32_t incl = chunks;
+#pragma unroll
+    for (uint32_t d = 1; d < 8u; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d);
+        if ((lane & 7u) >= d) incl += v;
+    }
+    const uint32_t excl = incl - chunks;
+    for (uint32_t turn = 0; turn < 8u; turn++) {
+        const uint32_t die = (blockIdx.x + turn) & 7u;
+        const uint32_t total = __shfl(incl, (int)(die * 8u + 7u));
+        uint32_t* const claim = L.claim + die * RDR_FRAG_CTR_STRIDE;
+        // somebody else's lists: not worth an atomic when they are known to be used up
+        if (turn && __hip_atomic_load(claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) continue;
+        for (;;) {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(claim, 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= total) break;  // every wave gets here: the counter only grows
+            const unsigned long long owner = __ballot((lane >> 3) == die && excl <= k && k < incl);  // exactly one lane
+            const int ol = __ffsll((long long)owner) - 1;
+            const uint32_t local = (k - (uint32_t)__shfl(excl, ol)) * 64u + lane;
+            if (local < (uint32_t)__shfl(cnt, ol)) {
+                const uint32_t f = (uint32_t)ol * L.cap + local;
+                const uint2 rec = L.recs[f];
+                float c[4];
+                shade_fragment<false, true>(fr, lights, lds_srgb, tris[rec.x], (int)(rec.y & 0xFFFFu), (int)(rec.y >> 16), c, lds_park + threadIdx.x);
+                L.cols[f] = pack_half4(c[0], c[1], c[2], c[3]);
+            }
+        }
+    }
+}
+
+// S == 1: writes hdr. S == 4: resolves straight into hdr, except in tiles whose blended-pass triangle list is not
+// empty (blend_start < blend_end): those keep their four sample colours in `samples_out` for the blended pass, which
+// resolves them afterwards.
+template <int S>
+__global__ void __launch_bounds__(256) k_frag_resolve(const DFrame* __restrict__ frp, FragLists L, uint2* __restrict__ hdr,
+                                                      uint2* __restrict__ samples_out, const uint32_t* __restrict__ blend_start,
+                                                      const uint32_t* __restrict__ blend_end) {
+    const DFrame& fr = *frp;
+    const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
+    const uint32_t tile = blockIdx.x;
+    const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
     if (!(px < (int)fr.W && py < (int)fr.H)) return;
     const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
-    const uint32_t tile = (uint32_t)ty * ((fr.W + RDR_TILE - 1) / RDR_TILE) + (uint32_t)tx;
-    const uint32_t before = state & 0xFFFFu;
+    const uint32_t state = L.pixel_state[(size_t)tile * 256u + threadIdx.x];
+    const uint32_t first = L.tile_first[tile] + (state & 0xFFFFu);
     uint32_t slot[S];
 #pragma unroll
     for (int s = 0; s < S; s++) { slot[s] = (state >> (16 + 4 * s)) & 15u; if (slot[s] == 15u) slot[s] = SHADE_NO_FRAGMENT; }
     bool any_sky = false;
 #pragma unroll
     for (int s = 0; s < S; s++) any_sky = any_sky || slot[s] == SHADE_NO_FRAGMENT;
-    uint2 sky_packed = make_uint2(0u, 0u);
+    uint2 sc[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) sc[s] = slot[s] == SHADE_NO_FRAGMENT ? make_uint2(0u, 0u) : L.cols[first + slot[s]];
     if (any_sky) {
         float sky[4];
         shade_sky(fr, px, py, sky);
-        sky_packed = pack_half4(sky[0], sky[1], sky[2], sky[3]);
-    }
-    uint2 sc[S];
+        const uint2 sky_packed = pack_half4(sky[0], sky[1], sky[2], sky[3]);
 #pragma unroll
-    for (int s = 0; s < S; s++) sc[s] = slot[s] == SHADE_NO_FRAGMENT ? sky_packed : lds_frag_col[before + slot[s]];
+        for (int s = 0; s < S; s++) if (slot[s] == SHADE_NO_FRAGMENT) sc[s] = sky_packed;
+    }
     const bool keep_samples = S > 1 && samples_out && blend_start[tile] < blend_end[tile];
     if (S == 1) {
         hdr[o] = sc[0];
@@ -575,102 +714,6 @@ RDR_DEV void resolve_pixel(const DFrame& fr, uint32_t state, const uint2* lds_fr
         }
         hdr[o] = pack_half4(sum[0] * (1.0f / S), sum[1] * (1.0f / S), sum[2] * (1.0f / S), sum[3] * (1.0f / S));
     }
-}
-
-// Opaque draws + skybox. S == 1: writes hdr. S == 4: resolves straight into
-// hdr, except in tiles whose blended-pass triangle list is not empty
-// (blend_start < blend_end): those keep their four sample colours in
-// `samples_out` for the blended pass, which resolves them afterwards.
-#ifndef RDR_SHADE_WAVES
-#define RDR_SHADE_WAVES 4  // waves per SIMD the register allocation is held to (128 VGPRs)
-#endif
-template <int S>
-__global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_opaque(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
-                                                      const DShadeTri* __restrict__ tris,
-                                                      const float* __restrict__ depth, const uint32_t* __restrict__ vis,
-                                                      uint2* __restrict__ hdr, uint2* __restrict__ samples_out,
-                                                      const uint32_t* __restrict__ blend_start, const uint32_t* __restrict__ blend_end,
-                                                      uint32_t n_tiles) {
-    __shared__ float lds_srgb[256];
-    __shared__ uint32_t lds_frag_id[256 * S];   // triangle id of fragment f
-    __shared__ uint8_t lds_frag_px[256 * S];    // its pixel = the thread index that owns the pixel
-    __shared__ uint2 lds_frag_col[256 * S];     // shaded colour, RGBA16F
-    __shared__ uint32_t lds_wave_total[4];
-    // What a pixel needs again after the fragment loop - which fragment each of its samples resolves to - waits in LDS
-    // meanwhile: values that live in registers across the loop are spilled by the compiler (the loop body takes the whole
-    // register budget), and a spill is a store that goes all the way to HBM.
-    __shared__ uint32_t lds_pixel_state[256];   // first fragment of the pixel | slot of sample s << (16 + 4 s)
-    __shared__ float lds_park[12 * 256];        // see shade_fragment
-    const DFrame& fr = *frp;
-    lds_srgb[threadIdx.x] = fr.srgb_decode[threadIdx.x];
-    const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
-    // block b belongs to die b % 8 and is that die's (b / 8)-th block
-    const uint32_t Q = RDR_SHADE_SQ_LOG2, side = 1u << Q;
-    const uint32_t nth = blockIdx.x >> 3, sq = (nth >> (2u * Q)) * 8u + (blockIdx.x & 7u), in_sq = nth & (side * side - 1u), sq_x = (tiles_x + side - 1u) >> Q;
-    const int tx = (int)((sq % sq_x) * side + (in_sq & (side - 1u))), ty = (int)((sq / sq_x) * side + (in_sq >> Q));
-    if ((uint32_t)tx >= tiles_x || (uint32_t)ty * tiles_x + (uint32_t)tx >= n_tiles) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool in_view = px < (int)fr.W && py < (int)fr.H;
-    const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
-
-    // ---- classify the samples of this pixel: sky, or the u-th distinct triangle of the pixel
-    uint32_t ids[S];
-    uint32_t slot[S];  // SHADE_NO_FRAGMENT = sky, else index among the pixel's distinct triangles
-    uint32_t n_unique = 0;
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        slot[s] = SHADE_NO_FRAGMENT;
-        if (!in_view) continue;
-        const uint32_t id = vis[s * plane_px + o];
-        const float zd = depth[s * plane_px + o];
-        if (id == 0xFFFFFFFFu || zd >= 1.0f) continue;
-        uint32_t u = n_unique;
-#pragma unroll
-        for (int k = S - 1; k >= 0; k--) if ((uint32_t)k < n_unique && ids[k] == id) u = (uint32_t)k;
-        if (u == n_unique) { ids[n_unique] = id; n_unique++; }
-        slot[s] = u;
-    }
-
-    // ---- exclusive prefix sum of n_unique (0..4) over the block: three ballots per wave, then the wave totals
-    uint32_t before = 0, wave_total = 0;
-#pragma unroll
-    for (int bit = 0; bit < 3; bit++) {
-        const unsigned long long m = __ballot((n_unique >> bit) & 1u);
-        before += (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) << bit;
-        wave_total += (uint32_t)__popcll(m) << bit;
-    }
-    if (lane == 0) lds_wave_total[wave] = wave_total;
-    __syncthreads();
-    uint32_t n_frag = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (w < wave) before += lds_wave_total[w];
-        n_frag += lds_wave_total[w];
-    }
-#pragma unroll
-    for (int k = 0; k < S; k++)
-        if ((uint32_t)k < n_unique) { lds_frag_id[before + k] = ids[k]; lds_frag_px[before + k] = (uint8_t)threadIdx.x; }
-    {
-        uint32_t st = before;  // < 1024
-#pragma unroll
-        for (int s = 0; s < S; s++) st |= (slot[s] & 15u) << (16 + 4 * s);  // SHADE_NO_FRAGMENT -> 15
-        lds_pixel_state[threadIdx.x] = st;
-    }
-    __syncthreads();
-
-    // ---- shade the fragment list densely
-    for (uint32_t f = threadIdx.x; f < n_frag; f += 256u) {
-        const uint32_t id = lds_frag_id[f], t = lds_frag_px[f];
-        const int fw = (int)(t >> 6), fl = (int)(t & 63u);
-        const int fx = tx * RDR_TILE + (fw & 1) * 8 + (fl & 7), fy = ty * RDR_TILE + (fw >> 1) * 8 + (fl >> 3);
-        float c[4];
-        shade_fragment<false, true>(fr, lights, lds_srgb, tris[id], fx, fy, c, lds_park + threadIdx.x);
-        lds_frag_col[f] = pack_half4(c[0], c[1], c[2], c[3]);
-    }
-    __syncthreads();
-    // ---- per pixel: sky where needed, gather the sample colours, store or resolve
-    resolve_pixel<S>(fr, lds_pixel_state[threadIdx.x], lds_frag_col, tx, ty, hdr, samples_out, blend_start, blend_end);
 }
 
 #define BLEND_CHUNK 64
@@ -907,15 +950,34 @@ void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, con
     hipLaunchKernelGGL(k_shade_setup, dim3((n_tris + 255) / 256), dim3(256), 0, s, fr, draws, first_tri, n_draws, n_tris, pair_offset, n_after,
                        pair_total, out);
 }
-void launch_shade_opaque(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const float* depth, const uint32_t* vis,
-                         void* hdr, void* samples_out, const uint32_t* blend_start, const uint32_t* blend_end, uint32_t W, uint32_t H) {
+uint32_t shade_frags_blocks_per_cu() { return RDR_SHADE_WAVES; }  // a 256-thread block is one wave per SIMD
+size_t shade_frag_slots(uint32_t W, uint32_t H, int samples) {
+    const uint32_t tiles_x = (W + RDR_TILE - 1) / RDR_TILE, tiles_y = (H + RDR_TILE - 1) / RDR_TILE;
+    return (size_t)RDR_FRAG_SEGS * ((tiles_x + 7u) / 8u) * ((tiles_y + 7u) / 8u) * 256u * (size_t)samples;
+}
+FragLists make_frag_lists(uint32_t W, uint32_t H, int samples, void* frag_recs, void* frag_cols, uint32_t* pixel_state, uint32_t* tile_first,
+                          uint32_t* list_count, uint32_t* list_claim) {
+    const uint32_t tiles_x = (W + RDR_TILE - 1) / RDR_TILE, tiles_y = (H + RDR_TILE - 1) / RDR_TILE;
+    FragLists L;
+    L.rect_w = (tiles_x + 7u) / 8u; L.rect_h = (tiles_y + 7u) / 8u;
+    L.cap = L.rect_w * L.rect_h * 256u * (uint32_t)samples;
+    L.count = list_count; L.claim = list_claim;
+    L.recs = (uint2*)frag_recs; L.cols = (uint2*)frag_cols; L.pixel_state = pixel_state; L.tile_first = tile_first;
+    return L;
+}
+void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const float* depth, const uint32_t* vis, const FragLists& L) {
+    const uint32_t grid = 64u * L.rect_w * L.rect_h;
+    if (samples == 1) hipLaunchKernelGGL(k_frag_classify<1>, dim3(grid), dim3(256), 0, s, fr, depth, vis, L);
+    else hipLaunchKernelGGL(k_frag_classify<4>, dim3(grid), dim3(256), 0, s, fr, depth, vis, L);
+}
+void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks) {
+    hipLaunchKernelGGL(k_shade_frags, dim3(blocks), dim3(256), 0, s, fr, lights, tris, L);
+}
+void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const FragLists& L, void* hdr, void* samples_out, const uint32_t* blend_start,
+                         const uint32_t* blend_end, uint32_t W, uint32_t H) {
     const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
-    const uint32_t side = 1u << RDR_SHADE_SQ_LOG2;
-    const uint32_t grid = ((((W + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) * (((H + RDR_TILE - 1) / RDR_TILE + side - 1u) / side) + 7u) / 8u * 8u * side * side;
-    if (samples == 1)
-        hipLaunchKernelGGL(k_shade_opaque<1>, dim3(grid), dim3(256), 0, s, fr, lights, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
-    else
-        hipLaunchKernelGGL(k_shade_opaque<4>, dim3(grid), dim3(256), 0, s, fr, lights, tris, depth, vis, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end, tiles);
+    if (samples == 1) hipLaunchKernelGGL(k_frag_resolve<1>, dim3(tiles), dim3(256), 0, s, fr, L, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end);
+    else hipLaunchKernelGGL(k_frag_resolve<4>, dim3(tiles), dim3(256), 0, s, fr, L, (uint2*)hdr, (uint2*)samples_out, blend_start, blend_end);
 }
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t tile0, uint32_t n_tiles, void* color,

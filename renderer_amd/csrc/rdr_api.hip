@@ -26,11 +26,15 @@ using namespace rdr;
 
 namespace {
 
-// d_counters: 64 bytes of scalar counters, then the spread counters. h_read (pinned) holds three copies of that block:
+// d_counters: 64 bytes of scalar counters, the spread counters, then (from RDR_COUNTER_LISTS on, never read back) the fill
+// counts of the opaque pass's fragment lists and the chunk counters of the eight dies, 128 bytes apart. h_read (pinned)
+// holds three copies of the first two parts:
 // [s * RDR_COUNTER_BYTES, +RDR_COUNTER_BYTES) for s = 0, 1 is what the end of a frame in slot s reads back (average
 // luminance in word RDR_COUNTER_LUM, spread counters from byte 64), [RDR_READ_MID, +RDR_COUNTER_BYTES) what a batch
 // reads back between its pair scan and its sort.
 #define RDR_COUNTER_BYTES (64u + RDR_BINNED_SLOTS * 128u)
+#define RDR_COUNTER_LISTS RDR_COUNTER_BYTES  // byte offset of the list counters inside a slot's block
+#define RDR_COUNTER_SLOT_BYTES (RDR_COUNTER_BYTES + (RDR_FRAG_SEGS + 8u) * RDR_FRAG_CTR_STRIDE * 4u)  // what a frame zeroes
 #define RDR_COUNTER_LUM 4u  // word of the scalar counters that the luminance reduction writes its result to
 #define RDR_COUNTER_FRAGS 5u  // word the blended pass counts its fragment-list slots in (zero after the frame's fill)
 #define RDR_READ_MID (2u * RDR_COUNTER_BYTES)
@@ -200,6 +204,9 @@ struct rdr_ctx {
     uint32_t batch_instances = 0;   // triangle instances of the last raster batch
     uint64_t blend_pairs = 0, blend_box_pixels = 0;  // of the last batch: (triangle, tile) pairs / box pixels of blended-view triangles
     DevBuf d_frags, d_frag_col, d_frag_head, d_tile_slots;
+    // opaque pass: fragment records and colours (one list per screen rectangle), per-pixel state, first fragment per tile
+    DevBuf d_ofrag_recs, d_ofrag_cols, d_pixel_state, d_tile_first;
+    uint32_t shade_blocks = 1024;  // grid of the fragment shading kernel: four 256-thread blocks per compute unit
     uint64_t blend_budget_slots = 48ull << 20;  // fragment-list slots (32 B each) a frame may use at once; RDR_BLEND_BUDGET_SLOTS overrides (tests)  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
 
     // Shadow views whose inputs did not change are not rendered again. `geometry_version` counts every call that can
@@ -260,7 +267,7 @@ int hip_fail(rdr_ctx* c, const char* what, hipError_t e) {
 
 // counters block of the frame being enqueued (each of the two frame slots has its own: the tail of a frame still
 // writes its block while the next frame has cleared and is filling the other)
-uint32_t* frame_counters(const rdr_ctx* c) { return (uint32_t*)(c->d_counters.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES); }
+uint32_t* frame_counters(const rdr_ctx* c) { return (uint32_t*)(c->d_counters.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_SLOT_BYTES); }
 
 double srgb_eotf(double v) { return v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); }
 
@@ -1101,6 +1108,10 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     if (!c) return RDR_ERR_DEVICE;
     c->settings = *settings; c->W = width; c->H = height; c->device = device;
     memset(&c->dir_light, 0, sizeof c->dir_light);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->shade_blocks = (uint32_t)cus * shade_frags_blocks_per_cu();
+    }
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
     for (int i = 0; i < 20 && ok; i++) ok = hipEventCreate(&c->ev_sets[i / 10][i % 10]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_pairs, hipEventDisableTiming) == hipSuccess;
@@ -1117,7 +1128,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
         tables[512 + i] = (float)srgb_eotf(((double)i + 0.5) / 255.0);
     }
     ok = ok && c->d_tables.ensure(768 * 4) == hipSuccess && hipMemcpy(c->d_tables.p, tables.data(), 768 * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && c->d_counters.ensure(2 * RDR_COUNTER_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, 2 * RDR_COUNTER_BYTES) == hipSuccess;
+    ok = ok && c->d_counters.ensure(2 * RDR_COUNTER_SLOT_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, 2 * RDR_COUNTER_SLOT_BYTES) == hipSuccess;
     ok = ok && c->d_frame.ensure(sizeof(DFrame) + 64) == hipSuccess;
     // this device's copy of the no-allocation scratch array (the device is current: hipSetDevice above)
     ok = ok && hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch)) == hipSuccess && c->noalloc_scratch != nullptr;
@@ -1151,7 +1162,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_env_b, &c->d_irradiance_b, &c->d_prefiltered_b, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
                       &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
-                      &c->d_counters, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_counters, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     DevBuf* alts[] = {&c->alt.batch_tables, &c->alt.frame, &c->alt.shade_tris, &c->alt.recs, &c->alt.keys[0], &c->alt.keys[1], &c->alt.vals[0],
@@ -1634,7 +1645,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         const char* e = getenv("RDR_DEVICE_DRAW_LISTS");
         c->device_draws = e ? atoi(e) != 0 : c->prims.size() >= 2048;
     }
-    HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_BYTES, c->stream));
+    HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_SLOT_BYTES, c->stream));
     if (c->device_draws) RDR_TRY(upload_cull_tables(c));  // the candidate lists the views below refer to
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     const vec3 cam_pos = c->camera.position;
@@ -1744,11 +1755,24 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     // from here on the frame runs on the shading stream, behind its own geometry phase (ev[1]) and, in stream order,
     // behind the previous frame's shading and tail
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev[1], 0));
-    HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
-    launch_shade_opaque(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), c->d_hdr.p,
-                        (S == 4 && have_blend) ? c->d_samples.p : nullptr, c->d_tile_start.as<uint32_t>() + blend_tile_base,
-                        c->d_tile_end.as<uint32_t>() + blend_tile_base, W, H);
-    HIP_TRY(hipEventRecord(c->ev[7], c->stream2));
+    {
+        const size_t slots = shade_frag_slots(W, H, (int)S);
+        const uint32_t n_tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
+        if (slots >= (1ull << 32)) return fail(c, RDR_ERR_CAPACITY, "render_frame: the image has more than 2^32 samples");
+        HIP_TRY(c->d_ofrag_recs.ensure(slots * 8));
+        HIP_TRY(c->d_ofrag_cols.ensure(slots * 8));
+        HIP_TRY(c->d_pixel_state.ensure((size_t)n_tiles * 256 * 4));
+        HIP_TRY(c->d_tile_first.ensure((size_t)n_tiles * 4));
+        uint32_t* list_count = frame_counters(c) + RDR_COUNTER_LISTS / 4u;
+        const FragLists L = make_frag_lists(W, H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(), c->d_tile_first.as<uint32_t>(),
+                                            list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
+        launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), L);
+        HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
+        launch_shade_frags(c->stream2, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, L, c->shade_blocks);
+        HIP_TRY(hipEventRecord(c->ev[7], c->stream2));
+        launch_frag_resolve(c->stream2, (int)S, c->d_frame.as<DFrame>(), L, c->d_hdr.p, (S == 4 && have_blend) ? c->d_samples.p : nullptr,
+                            c->d_tile_start.as<uint32_t>() + blend_tile_base, c->d_tile_end.as<uint32_t>() + blend_tile_base, W, H);
+    }
     HIP_TRY(hipGetLastError());
 
     // ---- blended draws, back to front; resolves its tiles into hdr
