@@ -150,14 +150,14 @@ def main():
     from renderer_amd.sharding import FrameSharder
     sharder = FrameSharder(r, dist=dist, device=f"cuda:{local_rank}", depth=2)
     frame_params = dict(exposure_mode=1, temporal_luminance=0.5)
-    acc = {"shade_kernel": 0.0, "raster_kernel": 0.0, "geometry": 0.0, "shade": 0.0, "bloom": 0.0, "tonemap": 0.0, "total": 0.0}
+    acc = {"shade_kernel": 0.0, "raster_kernel": 0.0, "geometry": 0.0, "shade": 0.0, "bloom": 0.0, "tonemap": 0.0, "total": 0.0, "host": 0.0}
     last_stats = [None]
 
     def after_render(_k):
         s = r.frame_stats()
         last_stats[0] = s
         acc["shade_kernel"] += s.ms_shade_kernel; acc["raster_kernel"] += s.ms_raster_kernel; acc["geometry"] += s.ms_geometry
-        acc["shade"] += s.ms_shade; acc["bloom"] += s.ms_bloom; acc["tonemap"] += s.ms_tonemap; acc["total"] += s.ms_total
+        acc["shade"] += s.ms_shade; acc["bloom"] += s.ms_bloom; acc["tonemap"] += s.ms_tonemap; acc["total"] += s.ms_total; acc["host"] += s.host_ms
 
     # every rank renders `warmup` then `steps` frames of the camera path: frame k of the job goes to rank k mod world
     sharder.run(a.warmup * world, camera_for_frame, frame_params)

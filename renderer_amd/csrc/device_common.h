@@ -188,19 +188,17 @@ RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, 
     }
 }
 
-// Variants for shading, where the result is continuous in the direction: the
-// face coordinates use the hardware reciprocal instead of two IEEE divides.
+// Variants for shading, where the result is continuous in the direction (filtering is seamless across cube edges, so
+// which of two tied faces is chosen does not show): the hardware's cube-map instructions select the face by the same
+// rule as cube_face above (z wins ties over y over x) and return sc, tc and twice the major axis; the division is
+// the hardware reciprocal.
 RDR_DEV int cube_face_fast(float rx, float ry, float rz, float& s, float& t) {
 #pragma clang fp contract(fast)
-    const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
-    int face; float sc, tc, ma;
-    if (az >= ax && az >= ay) { face = rz < 0.0f ? 5 : 4; sc = rz < 0.0f ? -rx : rx; tc = -ry; ma = az; }
-    else if (ay >= ax) { face = ry < 0.0f ? 3 : 2; sc = rx; tc = ry < 0.0f ? -rz : rz; ma = ay; }
-    else { face = rx < 0.0f ? 1 : 0; sc = rx < 0.0f ? rz : -rz; tc = -ry; ma = ax; }
-    const float hinv = 0.5f * __builtin_amdgcn_rcpf(ma);
+    const float sc = __builtin_amdgcn_cubesc(rx, ry, rz), tc = __builtin_amdgcn_cubetc(rx, ry, rz);
+    const float hinv = __builtin_amdgcn_rcpf(fabsf(__builtin_amdgcn_cubema(rx, ry, rz)));  // 1 / (2 |major axis|)
     s = fminf(fmaxf(fmaf(sc, hinv, 0.5f), 0.0f), 1.0f);
     t = fminf(fmaxf(fmaf(tc, hinv, 0.5f), 0.0f), 1.0f);
-    return face;
+    return (int)__builtin_amdgcn_cubeid(rx, ry, rz);
 }
 // `cube` is a bordered copy (k_cube_border): the footprint at (i0, j0), i0 and j0 in [-1, r - 1], is two pairs of
 // neighbouring words, no edge handling.
