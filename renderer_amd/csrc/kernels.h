@@ -79,7 +79,7 @@ size_t shade_frag_slots(uint32_t W, uint32_t H, int samples);  // slots of recs 
 uint32_t shade_frags_blocks_per_cu();  // blocks of k_shade_frags that fit a compute unit
 FragLists make_frag_lists(uint32_t W, uint32_t H, int samples, void* frag_recs, void* frag_cols, uint32_t* pixel_state, uint32_t* tile_first,
                           uint32_t* list_count, uint32_t* list_claim);
-void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const float* depth, const uint32_t* vis, const FragLists& L);
+void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const uint32_t* vis, const FragLists& L);
 void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks);
 void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const FragLists& L, void* hdr, void* samples_out, const uint32_t* blend_start,
                          const uint32_t* blend_end, uint32_t W, uint32_t H);

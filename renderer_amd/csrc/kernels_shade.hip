@@ -111,6 +111,34 @@ RDR_DEV BrdfFrag brdf_frag(F3 N, F3 V, F3 albedo, float roughness, float metalli
     f.c4 = 4.0f * f.NV1;
     return f;
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+RDR_DEV v2f v2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+RDR_DEV v2f v2s(float a) { return v2(a, a); }
+// brdf_eval below for two lights at once, one per vector component: the sums, products and fused multiply-adds are
+// two-component instructions, only the reciprocals, square roots and min / max work on one component at a time.
+RDR_DEV void brdf_eval2(const BrdfFrag& f, v2f LL, v2f NL, v2f VL, v2f& r, v2f& g, v2f& b) {
+#pragma clang fp contract(fast)
+    const v2f t = 2.0f * VL + (1.0f + LL);
+    const v2f rs = v2(__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y));
+    v2f NdotH = (f.NV + NL) * rs, HdotV = (1.0f + VL) * rs;
+    NdotH = v2(clampf(NdotH.x, 0.0f, 1.0f), clampf(NdotH.y, 0.0f, 1.0f));
+    HdotV = v2(clampf(HdotV.x, 0.0f, 1.0f), clampf(HdotV.y, 0.0f, 1.0f));
+    v2f dd = NdotH * NdotH * f.a2m1 + 1.0f;
+    dd = kPI * dd * dd;
+    const v2f NL1 = v2(fmaxf(NL.x, 1e-3f), fmaxf(NL.y, 1e-3f));
+    const v2f gden = NL1 * f.omk + f.k;
+    v2f sden = f.c4 * NL1;
+    sden = v2(fmaxf(sden.x, 1e-5f), fmaxf(sden.y, 1e-5f));
+    const v2f G = NL1 * v2(fast_rcp(gden.x), fast_rcp(gden.y)) * f.gv;
+    const v2f spec = f.a2 * v2(fast_rcp(dd.x), fast_rcp(dd.y)) * G * v2(fast_rcp(sden.x), fast_rcp(sden.y));
+    const v2f x = 1.0f - HdotV;
+    const v2f x2 = x * x, x5 = x2 * x2 * x;
+    const v2f NdotL = v2(fmaxf(NL.x, 0.0f), fmaxf(NL.y, 0.0f));
+    const v2f Fx = f.F0.x + f.omF0.x * x5, Fy = f.F0.y + f.omF0.y * x5, Fz = f.F0.z + f.omF0.z * x5;
+    r = ((f.kdiff.x - Fx * f.kdiff.x) + spec * Fx) * NdotL;
+    g = ((f.kdiff.y - Fy * f.kdiff.y) + spec * Fy) * NdotL;
+    b = ((f.kdiff.z - Fz * f.kdiff.z) + spec * Fz) * NdotL;
+}
 // BRDF(1, L, ...) of pbr.frag: the outgoing radiance per unit of light radiance, cosine term included. L need not be
 // normalised (the reference passes the raw light vector for lights without a shadow map, pbr.frag:157-158): LL = L.L,
 // NL = N.L, VL = V.L. The half vector never materialises: with |V| = 1, |V + L|^2 = 1 + 2 V.L + L.L,
@@ -419,52 +447,49 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
     // ---- point lights (pbr.frag:123-160)
     // depth of the cube-face projection (near .1, far 100): (far - far*near/d) / (far - near) = c0 - c1 / d
     const float c0 = 100.0f / (100.0f - 0.1f), c1 = (100.0f * 0.1f) / (100.0f - 0.1f);
-    // RDR_LIGHT_GROUP lights at a time, in two phases: first the light vectors and the shadow-map lookups of the group
-    // (their loads overlap), then the BRDFs. The light records are read through a kernel argument with a uniform index:
-    // scalar loads into scalar registers. Whether a light casts shadows is uniform, so that branch costs nothing.
-#ifndef RDR_LIGHT_GROUP
-#define RDR_LIGHT_GROUP 2
-#endif
-    const uint32_t n_lights = (RDR_DIAG & 16) ? 0u : fr.n_lights;
-    for (uint32_t base = 0; base < n_lights; base += RDR_LIGHT_GROUP) {
-        float d2[RDR_LIGHT_GROUP], sh[RDR_LIGHT_GROUP], nl[RDR_LIGHT_GROUP], vl[RDR_LIGHT_GROUP];
+    // Two lights at a time (a DPointLight record), in two phases: first the light vectors and the shadow-map look-ups of
+    // the pair (their loads overlap), then both BRDFs in two-component arithmetic. The records are read through a kernel
+    // argument with a uniform index: scalar loads into scalar registers. Whether a light casts shadows is uniform, so
+    // that branch costs nothing.
+    const uint32_t n_pairs = (RDR_DIAG & 16) ? 0u : (fr.n_lights + 1u) >> 1;
+    v2f LoR = v2s(0.0f), LoG = v2s(0.0f), LoB = v2s(0.0f);  // what the first / second lights of the pairs add
+    for (uint32_t p = 0; p < n_pairs; p++) {
+        const DPointLight pl = lights[p];
+        const v2f Lx = v2(pl.px[0], pl.px[1]) - P.x, Ly = v2(pl.py[0], pl.py[1]) - P.y, Lz = v2(pl.pz[0], pl.pz[1]) - P.z;
+        const v2f d2 = __builtin_elementwise_fma(Lz, Lz, __builtin_elementwise_fma(Ly, Ly, Lx * Lx));  // distance^2
+        const v2f nl = __builtin_elementwise_fma(v2s(N.z), Lz, __builtin_elementwise_fma(v2s(N.y), Ly, N.x * Lx));
+        const v2f vl = __builtin_elementwise_fma(v2s(V.z), Lz, __builtin_elementwise_fma(v2s(V.y), Ly, V.x * Lx));
+        float sh[2];
 #pragma unroll
-        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
-            sh[j] = 0.0f; d2[j] = 1.0f; nl[j] = 0.0f; vl[j] = 0.0f;
-            if (base + j >= n_lights) continue;  // uniform
-            const DPointLight pl = lights[base + j];
-            const F3 Lv = f3(pl.px, pl.py, pl.pz) - P;
-            d2[j] = dot3f(Lv, Lv);  // distance^2
-            nl[j] = dot3f(N, Lv);
-            vl[j] = dot3f(V, Lv);
+        for (int j = 0; j < 2; j++) {
             // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says.
-            // No per-lane branch here: the look-ups of the group's lights then sit in one block of code and their loads
-            // are in flight together; a lane that does not need the result computes it on a valid address and drops it.
-            const bool lit = nl[j] > 0.0f;
+            // No per-lane branch here: the look-ups of the pair then sit in one block of code and their loads are in
+            // flight together; a lane that does not need the result computes it on a valid address and drops it.
             float shadowTest = 1.0f;
-            if ((pl.flags & 1u) && (pl.flags & 2u) && !(RDR_DIAG & 32)) {  // uniform
-                const float lightDepth = fmaxf(fabsf(Lv.x), fmaxf(fabsf(Lv.y), fabsf(Lv.z))) - 0.05f;
+            if ((pl.flags[j] & 3u) == 3u && !(RDR_DIAG & 32)) {  // uniform: casts shadows and has a map
+                const float lx = Lx[j], ly = Ly[j], lz = Lz[j];
+                const float lightDepth = fmaxf(fabsf(lx), fmaxf(fabsf(ly), fabsf(lz))) - 0.05f;
                 const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
-                shadowTest = shadow_cube(fr, pl.slot, -Lv.x, -Lv.y, -Lv.z, ref);
+                shadowTest = shadow_cube(fr, pl.slot[j], -lx, -ly, -lz, ref);
                 shadowTest = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
             }
-            sh[j] = lit ? shadowTest : 0.0f;
+            sh[j] = nl[j] > 0.0f ? shadowTest : 0.0f;
         }
-#pragma unroll
-        for (int j = 0; j < RDR_LIGHT_GROUP; j++) {
-            if (base + j >= n_lights) continue;
-            const DPointLight pl = lights[base + j];
-            // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
-            const bool on = !(fmaxf(pl.ix, fmaxf(pl.iy, pl.iz)) <= 1e-3f * d2[j]) && sh[j] != 0.0f;
-            if (!__any(on)) continue;  // uniform
-            // a light with a shadow map uses the normalised direction, one without does not (pbr.frag:154-158)
-            const bool unit = (pl.flags & 1u) && (pl.flags & 2u);
-            const float ls = unit ? __builtin_amdgcn_rsqf(d2[j]) : 1.0f;
-            const F3 r = brdf_eval(bf, unit ? 1.0f : d2[j], nl[j] * ls, vl[j] * ls);
-            const float w = on ? fast_rcp(d2[j]) * sh[j] : 0.0f;  // attenuation x shadow
-            Lo = Lo + f3(r.x * (pl.ix * w), r.y * (pl.iy * w), r.z * (pl.iz * w));
-        }
+        // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
+        const bool on0 = !(fmaxf(pl.ix[0], fmaxf(pl.iy[0], pl.iz[0])) <= 1e-3f * d2.x) && sh[0] != 0.0f;
+        const bool on1 = !(fmaxf(pl.ix[1], fmaxf(pl.iy[1], pl.iz[1])) <= 1e-3f * d2.y) && sh[1] != 0.0f;
+        if (!__any(on0 || on1)) continue;  // uniform
+        // a light with a shadow map uses the normalised direction, one without does not (pbr.frag:154-158)
+        const bool unit0 = (pl.flags[0] & 3u) == 3u, unit1 = (pl.flags[1] & 3u) == 3u;
+        const v2f ls = v2(unit0 ? __builtin_amdgcn_rsqf(d2.x) : 1.0f, unit1 ? __builtin_amdgcn_rsqf(d2.y) : 1.0f);
+        v2f r, g, b;
+        brdf_eval2(bf, v2(unit0 ? 1.0f : d2.x, unit1 ? 1.0f : d2.y), nl * ls, vl * ls, r, g, b);
+        const v2f w = v2(on0 ? fast_rcp(d2.x) * sh[0] : 0.0f, on1 ? fast_rcp(d2.y) * sh[1] : 0.0f);  // attenuation x shadow
+        LoR += r * (v2(pl.ix[0], pl.ix[1]) * w);
+        LoG += g * (v2(pl.iy[0], pl.iy[1]) * w);
+        LoB += b * (v2(pl.iz[0], pl.iz[1]) * w);
     }
+    Lo = Lo + f3(LoR.x + LoR.y, LoG.x + LoG.y, LoB.x + LoB.y);
 
     // ---- directional light with cascaded shadow maps (pbr.frag:163-183, basic.vert:45-48)
     // (a surface facing away from the light gets max(N.L, 0) = 0 from it: no cascade look-up, no BRDF)
@@ -550,8 +575,7 @@ __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ 
 // run dry takes chunks from the next die's lists, so no die idles at the end. List order inside a rectangle is the
 // order in which its tiles' blocks arrive; colours do not depend on it.
 template <int S>
-__global__ void __launch_bounds__(256) k_frag_classify(const DFrame* __restrict__ frp, const float* __restrict__ depth,
-                                                       const uint32_t* __restrict__ vis, FragLists L) {
+__global__ void __launch_bounds__(256) k_frag_classify(const DFrame* __restrict__ frp, const uint32_t* __restrict__ vis, FragLists L) {
     __shared__ uint32_t lds_wave_total[4];
     __shared__ uint32_t lds_base;
     const DFrame& fr = *frp;
@@ -562,8 +586,9 @@ __global__ void __launch_bounds__(256) k_frag_classify(const DFrame* __restrict_
     const uint32_t tx = gx * L.rect_w + in_rect % L.rect_w, ty = gy * L.rect_h + in_rect / L.rect_w;
     if (tx >= tiles_x || ty >= tiles_y) return;
     const uint32_t list = ((gx + gy) & 7u) * 8u + gy;
+    // thread t owns pixel (t % 16, t / 16) of the tile: a wave reads and writes whole rows of it
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = (int)tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = (int)ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int px = (int)tx * RDR_TILE + (int)(threadIdx.x & 15u), py = (int)ty * RDR_TILE + (int)(threadIdx.x >> 4);
     const bool in_view = px < (int)fr.W && py < (int)fr.H;
     const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
 
@@ -575,9 +600,9 @@ __global__ void __launch_bounds__(256) k_frag_classify(const DFrame* __restrict_
     for (int s = 0; s < S; s++) {
         slot[s] = 15u;
         if (!in_view) continue;
+        // a sample that holds a triangle id passed the LESS test against the cleared depth 1.0: no look at its depth
         const uint32_t id = vis[s * plane_px + o];
-        const float zd = depth[s * plane_px + o];
-        if (id == 0xFFFFFFFFu || zd >= 1.0f) continue;
+        if (id == 0xFFFFFFFFu) continue;
         uint32_t u = n_unique;
 #pragma unroll
         for (int k = S - 1; k >= 0; k--) if ((uint32_t)k < n_unique && ids[k] == id) u = (uint32_t)k;
@@ -675,8 +700,7 @@ __global__ void __launch_bounds__(256) k_frag_resolve(const DFrame* __restrict__
     const uint32_t tiles_x = (fr.W + RDR_TILE - 1) / RDR_TILE;
     const uint32_t tile = blockIdx.x;
     const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px = tx * RDR_TILE + (wave & 1) * 8 + (lane & 7), py = ty * RDR_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const int px = tx * RDR_TILE + (int)(threadIdx.x & 15u), py = ty * RDR_TILE + (int)(threadIdx.x >> 4);  // as in k_frag_classify
     if (!(px < (int)fr.W && py < (int)fr.H)) return;
     const size_t plane_px = (size_t)fr.W * fr.H, o = (size_t)py * fr.W + px;
     const uint32_t state = L.pixel_state[(size_t)tile * 256u + threadIdx.x];
@@ -965,10 +989,10 @@ FragLists make_frag_lists(uint32_t W, uint32_t H, int samples, void* frag_recs, 
     L.recs = (uint2*)frag_recs; L.cols = (uint2*)frag_cols; L.pixel_state = pixel_state; L.tile_first = tile_first;
     return L;
 }
-void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const float* depth, const uint32_t* vis, const FragLists& L) {
+void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const uint32_t* vis, const FragLists& L) {
     const uint32_t grid = 64u * L.rect_w * L.rect_h;
-    if (samples == 1) hipLaunchKernelGGL(k_frag_classify<1>, dim3(grid), dim3(256), 0, s, fr, depth, vis, L);
-    else hipLaunchKernelGGL(k_frag_classify<4>, dim3(grid), dim3(256), 0, s, fr, depth, vis, L);
+    if (samples == 1) hipLaunchKernelGGL(k_frag_classify<1>, dim3(grid), dim3(256), 0, s, fr, vis, L);
+    else hipLaunchKernelGGL(k_frag_classify<4>, dim3(grid), dim3(256), 0, s, fr, vis, L);
 }
 void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks) {
     hipLaunchKernelGGL(k_shade_frags, dim3(blocks), dim3(256), 0, s, fr, lights, tris, L);

@@ -1706,10 +1706,16 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
             memcpy(fr.dir_I, c->dir_light.intensity, 12);
         }
         fr.dir_shadow = c->d_dir_shadow.as<float>(); fr.point_shadow = c->d_point_shadow.as<float>();
-        std::vector<DPointLight> dl(std::max<size_t>(c->lights.size(), 1));
+        std::vector<DPointLight> dl(std::max<size_t>((c->lights.size() + 1) / 2, 1));
+        memset(dl.data(), 0, dl.size() * sizeof(DPointLight));
         for (size_t i = 0; i < c->lights.size(); i++) {
             const HostLight& l = c->lights[i];
-            dl[i] = DPointLight{l.point.x, l.point.y, l.point.z, l.intensity.x, l.intensity.y, l.intensity.z, l.flags, l.slot};
+            DPointLight& d = dl[i / 2];
+            const int j = (int)(i & 1);
+            d.px[j] = l.point.x; d.py[j] = l.point.y; d.pz[j] = l.point.z;
+            d.ix[j] = l.intensity.x; d.iy[j] = l.intensity.y; d.iz[j] = l.intensity.z;
+            d.flags[j] = l.flags; d.slot[j] = l.slot;
+            if (j == 0) { d.px[1] = d.px[0]; d.py[1] = d.py[0]; d.pz[1] = d.pz[0]; }  // stands in for a missing second light
         }
         const size_t sz_l = dl.size() * sizeof(DPointLight), off_l = (sizeof(DFrame) + 15) & ~(size_t)15;
         HIP_TRY(c->d_frame.ensure(off_l + sz_l));
@@ -1766,7 +1772,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         uint32_t* list_count = frame_counters(c) + RDR_COUNTER_LISTS / 4u;
         const FragLists L = make_frag_lists(W, H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(), c->d_tile_first.as<uint32_t>(),
                                             list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
-        launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), L);
+        launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_vis.as<uint32_t>(), L);
         HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
         launch_shade_frags(c->stream2, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, L, c->shade_blocks);
         HIP_TRY(hipEventRecord(c->ev[7], c->stream2));

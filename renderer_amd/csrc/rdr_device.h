@@ -145,12 +145,16 @@ struct alignas(16) DShadeTri {
 };  // 384 bytes = 24 x 16
 #define RDR_SHADE_TRI_VEC4 24
 
+// Point lights 2k and 2k + 1 side by side, component by component: the shading kernels read the record with scalar
+// loads and work on both lights of a pair at once (two-component vector instructions take a component pair straight
+// from two neighbouring scalar registers). The second light of the last pair of an odd number of lights has zero
+// intensity (which the light cut-off of pbr.frag:133 drops), flags 0 and the position of the first.
 struct DPointLight {
-    float px, py, pz;
-    float ix, iy, iz;
-    uint32_t flags;
-    uint32_t slot;
-};
+    float px[2], py[2], pz[2];
+    float ix[2], iy[2], iz[2];
+    uint32_t flags[2];
+    uint32_t slot[2];
+};  // 64 bytes
 
 struct DCube {
     const uint32_t* texels;  // B10G11R11 packed, level-major, face-major inside a level
