@@ -234,9 +234,9 @@ def main():
                                    f"{a.tex}^2 textures, dir light 4x2048^2 cascades + 16 point lights (8 shadowed, 512^2 cubes), IBL, bloom+tonemap",
                        "parallelism": f"frame-sharded x{world}, RCCL gather of RGBA8 frames to rank 0" if world > 1 else "single GPU",
                        "lavapipe_oracle": "not available; CPU restatement used"},
-            "roofline": {"kernel": "k_shade_opaque", "bound": "valu_fp32", "achieved": shade_tf, "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": shade_tf / VALU_FP32_PEAK_TF, "traffic": measured_traffic("k_shade_opaque<4>"), "ms": shade_ms,
-                         "algorithmic": f"{shade_flops_per_px(n_lights):.0f} flop/px x {n_px} px", "valu_measured": measured_valu("k_shade_opaque")},
+            "roofline": {"kernel": "k_shade_frags", "bound": "valu_fp32", "achieved": shade_tf, "peak": VALU_FP32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": shade_tf / VALU_FP32_PEAK_TF, "traffic": measured_traffic("k_shade_frags"), "ms": shade_ms,
+                         "algorithmic": f"{shade_flops_per_px(n_lights):.0f} flop/px x {n_px} px", "valu_measured": measured_valu("k_shade_frags")},
             "roofline_passes": [
                 {"pass": "bloom chain + tonemap + luminance", "bound": "hbm", "achieved": post_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": post_gbs / HBM_PEAK_GBS, "ms": post_ms, "algorithmic": f"{POST_BYTES_PER_PX} B/px x {n_px} px",
