@@ -54,8 +54,11 @@ struct RasterViews {
     uint32_t base[RDR_RASTER_MAX_VIEWS];  // first tile of view k (0xFFFFFFFF past the last)
     DView v[RDR_RASTER_MAX_VIEWS];
 };
+// `classify`: for the 4x view of a frame, the fragment lists of the opaque pass, filled from the tiles' samples while
+// they are still in LDS (then launch_frag_classify is not needed); null otherwise
+struct FragLists;
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DView* d_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples);
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples, const FragLists* classify = nullptr);
 
 // kernels_shade.hip
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,

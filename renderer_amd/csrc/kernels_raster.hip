@@ -517,9 +517,15 @@ __global__ void __launch_bounds__(256) k_view_init(const DView* __restrict__ vie
     vw.depth[at] = vw.init[at];
 }
 
-template <int S, int T, int RASTER_CHUNK, int TILES>
+// CLASSIFY (the 4x view of a frame): the tile's samples are also turned into the fragment lists the opaque shading works
+// from, while they are still in LDS - the distinct triangles of every pixel's samples -> (triangle, pixel) records
+// appended to the list of the tile's screen rectangle, a state word per pixel, the position of the tile's first
+// fragment (FragLists, kernels.h; k_frag_classify in kernels_shade.hip does the same from the visibility image).
+template <int S, int T, int RASTER_CHUNK, int TILES, bool CLASSIFY>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_raster(const RasterViews tbl, const DTriRec* __restrict__ recs, const uint32_t* __restrict__ sorted_vals,
-                                              const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_end) {
+                                              const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_end, const FragLists fl) {
+    static_assert(!CLASSIFY || S == 4, "fragment lists are built for the multisampled main view");
+    __shared__ uint32_t lds_cls[CLASSIFY ? (256 / 64) + 1 : 1];  // fragments per (pixel group, wave), then the tile's first fragment
     constexpr int Q = 256 / T;  // pixels of the tile per thread: pixel q*T + tid
     static_assert(RASTER_CHUNK <= 64 && (RASTER_CHUNK & (RASTER_CHUNK - 1)) == 0 && RASTER_CHUNK <= T, "one lane of wave 0 per staged record");
     __shared__ __attribute__((aligned(16))) uint32_t lds_rec[RASTER_CHUNK * 32];  // records of 128 bytes
@@ -567,7 +573,9 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
                     if (vw.vis) vw.vis[s * plane_px + at] = RDR_PAIR_INVALID;
                 }
             }
+            if (CLASSIFY) fl.pixel_state[(size_t)local_tile * 256u + (uint32_t)pix] = 0xFFFF0000u;  // no fragment, every sample sky
         }
+        if (CLASSIFY && tid == 0) fl.tile_first[local_tile] = 0u;
         continue;
     }
 
@@ -733,10 +741,13 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
         }
     }
     __syncthreads();
+    uint32_t cls_ids[CLASSIFY ? Q : 1][S], cls_state[CLASSIFY ? Q : 1], cls_n[CLASSIFY ? Q : 1];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int pix = q * T + tid, px = ox0 + (pix & 15), py = oy0 + (pix >> 4);
-        if (!(px < (int)vw.w && py < (int)vw.h)) continue;
+        const bool in_view = px < (int)vw.w && py < (int)vw.h;
+        if (CLASSIFY) { cls_n[q] = 0u; cls_state[q] = 0xFFFF0000u; }
+        if (!in_view) continue;
         const size_t o = (size_t)py * vw.pitch + px;
         unsigned long long key[S];
 #pragma unroll
@@ -744,10 +755,76 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
         // every pixel is stored, changed or not: whole sectors go out, none has to be merged in memory
 #pragma unroll
         for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
+        uint32_t vid[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) vid[s] = key[s] != ((unsigned long long)(S == 1 ? zi1[q] : ONE) << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
         if (vw.vis) {
 #pragma unroll
-            for (int s = 0; s < S; s++)
-                vw.vis[s * plane_px + o] = key[s] != ((unsigned long long)(S == 1 ? zi1[q] : ONE) << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
+            for (int s = 0; s < S; s++) vw.vis[s * plane_px + o] = vid[s];
+        }
+        if (CLASSIFY) {
+            // the u-th distinct triangle of the pixel (15: the sample saw none)
+            uint32_t n_unique = 0u, st = 0u;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                uint32_t u = 15u;
+                if (vid[s] != RDR_PAIR_INVALID) {
+                    u = n_unique;
+#pragma unroll
+                    for (int k = S - 1; k >= 0; k--) if ((uint32_t)k < n_unique && cls_ids[q][k] == vid[s]) u = (uint32_t)k;
+                    if (u == n_unique) { cls_ids[q][n_unique] = vid[s]; n_unique++; }
+                }
+                st |= u << (16 + 4 * s);
+            }
+            cls_n[q] = n_unique; cls_state[q] = st;
+        }
+    }
+    if (CLASSIFY) {
+        // exclusive prefix sum of the fragment counts (0..4) in pixel order: pixel q * T + tid, so group q before q + 1,
+        // inside a group wave after wave; three ballots per group and wave, then the totals through LDS
+        constexpr int NW = T / 64;
+        const int wave = tid >> 6, lane = tid & 63;
+        uint32_t before[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            uint32_t b = 0u, tot = 0u;
+#pragma unroll
+            for (int bit = 0; bit < 3; bit++) {
+                const unsigned long long m = __ballot((cls_n[q] >> bit) & 1u);
+                b += (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) << bit;
+                tot += (uint32_t)__popcll(m) << bit;
+            }
+            before[q] = b;
+            if (lane == 0) lds_cls[q * NW + wave] = tot;
+        }
+        __syncthreads();
+        uint32_t n_frag = 0u;
+#pragma unroll
+        for (int j = 0; j < Q * NW; j++) {
+            const uint32_t v = lds_cls[j];
+#pragma unroll
+            for (int q = 0; q < Q; q++) if (j < q * NW + wave) before[q] += v;
+            n_frag += v;
+        }
+        const uint32_t tx = local_tile % vw.tiles_x, ty = local_tile / vw.tiles_x;
+        const uint32_t gx = tx / fl.rect_w, gy = ty / fl.rect_h;
+        const uint32_t list = ((gx + gy) & 7u) * 8u + gy;
+        __syncthreads();  // everybody has read the totals: the last word now carries the tile's first fragment
+        if (tid == 0) {
+            const uint32_t at = n_frag ? atomicAdd(fl.count + list * RDR_FRAG_CTR_STRIDE, n_frag) : 0u;  // <= cap - n_frag: the list holds every sample of its rectangle
+            lds_cls[256 / 64] = list * fl.cap + at;
+            fl.tile_first[local_tile] = list * fl.cap + at;
+        }
+        __syncthreads();
+        const uint32_t first = lds_cls[256 / 64];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int pix = q * T + tid, px = ox0 + (pix & 15), py = oy0 + (pix >> 4);
+            const uint32_t xy = (uint32_t)px | ((uint32_t)py << 16);
+#pragma unroll
+            for (int k = 0; k < S; k++)
+                if ((uint32_t)k < cls_n[q]) fl.recs[first + before[q] + k] = make_uint2(cls_ids[q][k], xy);
+            fl.pixel_state[(size_t)local_tile * 256u + (uint32_t)pix] = cls_state[q] | before[q];  // before < 1024
         }
     }
     }  // tiles of the block
@@ -779,7 +856,7 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32
 // `samples`, RDR_RASTER_MAX_VIEWS of them per launch. `views` is the host copy of the batch's view table, `d_views` the
 // device copy (single-sampled targets are first brought to their initial state from it, k_view_init).
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DView* d_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples) {
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples, const FragLists* classify) {
     if (r.first_tile >= r.end_tile) return;
     uint32_t last = r.first_view;
     while (last + 1 < n_views && views[last + 1].tile_base < r.end_tile) last++;
@@ -798,11 +875,15 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DV
         const DView& lv = tbl.v[tbl.n - 1];
         tbl.end_tile = lv.tile_base + lv.tiles_x * lv.tiles_y;
         const uint32_t n_tiles = tbl.end_tile - tbl.first_tile;
+        const FragLists none{};
         if (samples == 1)
-            hipLaunchKernelGGL((k_raster<1, RDR_RASTER_T1, RDR_RASTER_C1, RDR_RASTER_K1>), dim3((n_tiles + RDR_RASTER_K1 - 1) / RDR_RASTER_K1), dim3(RDR_RASTER_T1), 0, s,
-                               tbl, recs, sorted_vals, tile_start, tile_end);
+            hipLaunchKernelGGL((k_raster<1, RDR_RASTER_T1, RDR_RASTER_C1, RDR_RASTER_K1, false>), dim3((n_tiles + RDR_RASTER_K1 - 1) / RDR_RASTER_K1), dim3(RDR_RASTER_T1), 0, s,
+                               tbl, recs, sorted_vals, tile_start, tile_end, none);
+        else if (classify && tbl.n == 1u)  // the lists are laid out for one view: the frame's main view
+            hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4, RDR_RASTER_K4, true>), dim3((n_tiles + RDR_RASTER_K4 - 1) / RDR_RASTER_K4), dim3(RDR_RASTER_T4), 0, s,
+                               tbl, recs, sorted_vals, tile_start, tile_end, *classify);
         else
-            hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4, RDR_RASTER_K4>), dim3((n_tiles + RDR_RASTER_K4 - 1) / RDR_RASTER_K4), dim3(RDR_RASTER_T4), 0, s,
-                               tbl, recs, sorted_vals, tile_start, tile_end);
+            hipLaunchKernelGGL((k_raster<4, RDR_RASTER_T4, RDR_RASTER_C4, RDR_RASTER_K4, false>), dim3((n_tiles + RDR_RASTER_K4 - 1) / RDR_RASTER_K4), dim3(RDR_RASTER_T4), 0, s,
+                               tbl, recs, sorted_vals, tile_start, tile_end, none);
     }
 }

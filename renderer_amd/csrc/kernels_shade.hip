@@ -66,7 +66,9 @@ RDR_DEV float shadow_pcf(const RDR_GLOBAL float* __restrict__ map, int res, floa
 }
 // samplerCubeArrayShadow. Every face is a (res + 2)^2 image whose border holds the depths across the cube edges
 // (seamless cube filtering), so the footprint is four neighbouring words wherever it lies.
-RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, float rz, float ref) {
+// A lane with `need` false gets a result it will drop: it reads the first words of the cube instead of its own
+// footprint, so that all such lanes of a wave share one cache line.
+RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, float rz, float ref, bool need) {
 #pragma clang fp contract(fast)
     const int res = (int)fr.point_res, pitch = res + 2;
     float s, t;
@@ -76,10 +78,10 @@ RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, f
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
     const int i0 = min(max((int)fu, -1), res - 1), j0 = min(max((int)fv, -1), res - 1);
-    const RDR_GLOBAL float* row = map + ((face * pitch + j0 + 1) * pitch + i0 + 1);
+    const RDR_GLOBAL float* row = map + (need ? (face * pitch + j0 + 1) * pitch + i0 + 1 : 0);
     float d00, d10, d01, d11;
     load_pair_f(row, d00, d10);
-    load_pair_f(row + pitch, d01, d11);
+    load_pair_f(row + (need ? pitch : 0), d01, d11);
     const float r00 = ref <= d00 ? 1.0f : 0.0f, r10 = ref <= d10 ? 1.0f : 0.0f;
     const float r01 = ref <= d01 ? 1.0f : 0.0f, r11 = ref <= d11 ? 1.0f : 0.0f;
     const float top = (1.0f - a) * r00 + a * r10, bot = (1.0f - a) * r01 + a * r11;
@@ -240,13 +242,15 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
 // pbr.frag at the centre of pixel (px,py) of the triangle whose vertex-stage outputs are in T.
 // MASKED = false for the opaque list, which holds no alpha-masked primitive: the cut-off test and its early
 // exit disappear and the five texture fetches can be in flight together.
+// `M`: a triangle record of the same primitive as T, where the material block and the texture descriptors are read
+// (they are the same in every record of a primitive: a wave whose lanes agree on M reads them from one cache line).
 // `park` (PARK): this thread's column of a [12][256] float array in LDS. The world position and the three
 // interpolated frame vectors are not needed while the textures are fetched and filtered - the part of the function
 // that takes every register there is - and wait there meanwhile (otherwise the compiler spills them, and more, to
 // scratch memory: stores that go out to HBM).
 template <bool MASKED, bool PARK>
-RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ lights, const float* srgb, const DShadeTri& T, int px, int py,
-                            float out[4], float* park) {
+RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ lights, const float* srgb, const DShadeTri& T, const DShadeTri& M,
+                            int px, int py, float out[4], float* park) {
     // Multiply-add pairs may fuse in this function: what must round as in the CPU checker is written with explicit
     // fma / fmaf calls or sits in the cascade block below, which switches fusing off again.
 #pragma clang fp contract(fast)
@@ -288,7 +292,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         __asm__ volatile("" ::: "memory");  // the values are read back below, not kept
     }
     __builtin_amdgcn_sched_barrier(0);  // the loads below stay below: the record is consumed in stages, not held whole
-    const DShadeTri& mt = T;  // material block and texture descriptors travel with the triangle
+    const DShadeTri& mt = M;  // material block and texture descriptors travel with the triangle
 
 #ifndef RDR_DIAG
 #define RDR_DIAG 0  // diagnostic builds only: bit 0 no textures, bit 1 no directional light, bit 2 no IBL, bit 3 nothing after interpolation, bit 4 no point lights, bit 5 no point-light shadow lookups
@@ -310,7 +314,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         // every one of them, without short-circuit evaluation): one memory round trip instead of one per texture
         DTexDesc td[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) td[k] = T.tex[k];
+        for (int k = 0; k < 5; k++) td[k] = M.tex[k];
         TexTaps taps0;
         tex_taps(td[0], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps0);
         const bool uniform_taps = (int)tex_pairs_adjacent(taps0) & (int)tex_same_geometry(td[1], td[0]) & (int)tex_same_geometry(td[2], td[0]) &
@@ -416,7 +420,12 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
             tex_axis(NdotV, w, 0u, i0, i1, a);
             tex_axis(roughness, h, 0u, j0, j1, b);
             const RDR_GLOBAL uint32_t* lp = as_global((const uint32_t*)fr.lut);
-            const uint32_t q00 = lp[j0 * w + i0], q10 = lp[j0 * w + i1], q01 = lp[j1 * w + i0], q11 = lp[j1 * w + i1];
+            // the two texels of a row are neighbours unless the footprint wraps around the edge (the table's buffer ends in
+            // spare words, so the pair at the last texel stays inside it)
+            uint32_t q00, q10, q01, q11;
+            load_pair(lp + (j0 * w + i0), q00, q10);
+            load_pair(lp + (j1 * w + i0), q01, q11);
+            if (i1 != i0 + 1) { q10 = lp[j0 * w + i1]; q11 = lp[j1 * w + i1]; }
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const float t00 = (float)((q00 >> (8 * k)) & 255u) * RDR_INV255, t10 = (float)((q10 >> (8 * k)) & 255u) * RDR_INV255;
@@ -470,7 +479,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
                 const float lx = Lx[j], ly = Ly[j], lz = Lz[j];
                 const float lightDepth = fmaxf(fabsf(lx), fmaxf(fabsf(ly), fabsf(lz))) - 0.05f;
                 const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
-                shadowTest = shadow_cube(fr, pl.slot[j], -lx, -ly, -lz, ref);
+                shadowTest = shadow_cube(fr, pl.slot[j], -lx, -ly, -lz, ref, nl[j] > 0.0f);
                 shadowTest = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
             }
             sh[j] = nl[j] > 0.0f ? shadowTest : 0.0f;
@@ -664,27 +673,62 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_frags(const DFra
         if ((lane & 7u) >= d) incl += v;
     }
     const uint32_t excl = incl - chunks;
+    // fragment this lane takes of chunk k of die `die` (its position in recs / cols), or ~0 past the end of the list
+    auto locate = [&](uint32_t die, uint32_t k) -> uint32_t {
+        const unsigned long long owner = __ballot((lane >> 3) == die && excl <= k && k < incl);  // exactly one lane
+        const int ol = __ffsll((long long)owner) - 1;
+        const uint32_t local = (k - (uint32_t)__shfl(excl, ol)) * 64u + lane;
+        return local < (uint32_t)__shfl(cnt, ol) ? (uint32_t)ol * L.cap + local : 0xFFFFFFFFu;
+    };
     for (uint32_t turn = 0; turn < 8u; turn++) {
         const uint32_t die = (blockIdx.x + turn) & 7u;
         const uint32_t total = __shfl(incl, (int)(die * 8u + 7u));
         uint32_t* const claim = L.claim + die * RDR_FRAG_CTR_STRIDE;
         // somebody else's lists: not worth an atomic when they are known to be used up
         if (turn && __hip_atomic_load(claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) continue;
+        // Chunks are claimed several at a time while the die's lists are far from used up (RDR_SHADE_BATCH of them in
+        // the first half, then fewer, single chunks over the last eighth, which evens the waves out at the end): a
+        // returning atomic on a word that hundreds of waves pull on takes microseconds.
+#ifndef RDR_SHADE_BATCH
+#define RDR_SHADE_BATCH 4u
+#endif
+        uint32_t batch = turn ? 1u : RDR_SHADE_BATCH;
         for (;;) {
             uint32_t k = 0;
-            if (lane == 0) k = atomicAdd(claim, 1u);
+            if (lane == 0) k = atomicAdd(claim, batch);
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= total) break;  // every wave gets here: the counter only grows
-            const unsigned long long owner = __ballot((lane >> 3) == die && excl <= k && k < incl);  // exactly one lane
-            const int ol = __ffsll((long long)owner) - 1;
-            const uint32_t local = (k - (uint32_t)__shfl(excl, ol)) * 64u + lane;
-            if (local < (uint32_t)__shfl(cnt, ol)) {
-                const uint32_t f = (uint32_t)ol * L.cap + local;
-                const uint2 rec = L.recs[f];
-                float c[4];
-                shade_fragment<false, true>(fr, lights, lds_srgb, tris[rec.x], (int)(rec.y & 0xFFFFu), (int)(rec.y >> 16), c, lds_park + threadIdx.x);
-                L.cols[f] = pack_half4(c[0], c[1], c[2], c[3]);
+            const uint32_t k_end = min(k + batch, total);
+            for (; k < k_end; k++) {  // uniform
+                const uint32_t f = locate(die, k);
+                uint2 colour = make_uint2(0u, 0u);
+                if (f != 0xFFFFFFFFu) {
+                    const uint2 rec = L.recs[f];
+                    // One record per primitive among the chunk's fragments stands in for the material of all of them
+                    // (the first lane's of each): one turn per distinct primitive, usually one or two.
+                    const uint32_t prim = tris[rec.x].prim;
+                    uint32_t mat_tri = rec.x;
+                    for (unsigned long long todo = __ballot(1); todo;) {
+                        const int l = __ffsll((long long)todo) - 1;
+                        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)prim, l), t = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, l);
+                        const bool same = prim == p;
+                        if (same) mat_tri = t;
+                        todo &= ~__ballot(same);
+                    }
+                    float c[4];
+                    shade_fragment<false, true>(fr, lights, lds_srgb, tris[rec.x], tris[mat_tri], (int)(rec.y & 0xFFFFu), (int)(rec.y >> 16), c,
+                                                lds_park + threadIdx.x);
+                    colour = pack_half4(c[0], c[1], c[2], c[3]);
+                }
+                // Where the colour goes is worked out again (by all lanes: the list's owner lane may hold no fragment of
+                // this chunk) rather than kept across the shading: one register less, which lets the register file take
+                // a wave of another kernel beside this one's four per SIMD.
+                uint32_t k_again = k;
+                asm volatile("" : "+s"(k_again));
+                const uint32_t f_again = locate(die, k_again);
+                if (f_again != 0xFFFFFFFFu) L.cols[f_again] = colour;
             }
+            batch = turn ? 1u : (k_end < (total >> 1) ? RDR_SHADE_BATCH : (k_end < total - (total >> 3) ? min(RDR_SHADE_BATCH, 2u) : 1u));
         }
     }
 }
@@ -921,7 +965,7 @@ __global__ void __launch_bounds__(256, 4) k_blend_shade(const DFrame* __restrict
         const uint4 m = frags[f];
         if (m.x == BLEND_NONE) continue;
         float c[4];
-        shade_fragment<true, true>(fr, lights, lds_srgb, tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c, lds_park + threadIdx.x);
+        shade_fragment<true, true>(fr, lights, lds_srgb, tris[m.x], tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c, lds_park + threadIdx.x);
         frag_col[f] = make_float4(c[0], c[1], c[2], c[3]);
     }
 }

@@ -247,7 +247,7 @@ struct rdr_ctx {
     hipStream_t stream3 = nullptr;
     hipStream_t stream4 = nullptr;  // the tail of a frame (bloom chain, tonemap, luminance, read-backs), beside the next frame's shading
     hipEvent_t ev_shaded[2] = {nullptr, nullptr};
-    struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr; } alt;
+    struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr, ofrag_recs, pixel_state, tile_first; } alt;
     PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
     unsigned char* noalloc_scratch = nullptr;  // address of `scratch` on this context's device
 };
@@ -780,7 +780,8 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
 
 // `after_scan`, if given, runs once set-up and the pair scan are enqueued and before the host waits for the pair
 // count: work enqueued there keeps the GPU busy while the host sizes the pair buffers.
-int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::function<int()>& after_scan = nullptr) {
+// `classify`: fragment lists the 4x rasteriser fills for the opaque pass (the frame's main batch), or null.
+int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::function<int()>& after_scan = nullptr, const FragLists* classify = nullptr) {
     if (b.views.empty()) return RDR_OK;
     uint32_t n_tiles = 0;
     int cur = 0;
@@ -804,7 +805,7 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
         launch_raster(st, b.views.data(), (uint32_t)b.views.size(), c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
                       c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s1, 1);
         launch_raster(st, b.views.data(), (uint32_t)b.views.size(), c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s4, 4);
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s4, 4, classify);
     };
     // RDR_SERIAL_RASTER: measurement aid, the rasterisers one after the other so that a profile shows each alone
     const bool side = rr[2].first_tile < rr[2].end_tile && (rr[0].first_tile < rr[0].end_tile || rr[1].first_tile < rr[1].end_tile) && !getenv("RDR_SERIAL_RASTER");
@@ -1134,6 +1135,8 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     ok = ok && hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch)) == hipSuccess && c->noalloc_scratch != nullptr;
     if (!ok) { rdr_destroy(c); return RDR_ERR_DEVICE; }
     if (const char* e = getenv("RDR_BLEND_BUDGET_SLOTS")) { const long long v = atoll(e); if (v > 0) c->blend_budget_slots = (uint64_t)v; }
+    // measurement aid: size of the fragment shading kernel's grid (a multiple of 8, one share per die)
+    if (const char* e = getenv("RDR_SHADE_BLOCKS")) { const long v = atol(e); if (v >= 8 && v <= 65536) c->shade_blocks = (uint32_t)v & ~7u; }
     c->camera.type = 0;  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
     c->camera.position = make3(0, 0, 0); c->camera.euler = make3(0, 0, 0);
     c->camera.near_plane = 0.1f; c->camera.far_plane = 60.0f;
@@ -1166,7 +1169,8 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
     DevBuf* alts[] = {&c->alt.batch_tables, &c->alt.frame, &c->alt.shade_tris, &c->alt.recs, &c->alt.keys[0], &c->alt.keys[1], &c->alt.vals[0],
-                      &c->alt.vals[1], &c->alt.tile_start, &c->alt.depth, &c->alt.vis, &c->alt.dir_shadow, &c->alt.hdr};
+                      &c->alt.vals[1], &c->alt.tile_start, &c->alt.depth, &c->alt.vis, &c->alt.dir_shadow, &c->alt.hdr, &c->alt.ofrag_recs,
+                      &c->alt.pixel_state, &c->alt.tile_first};
     for (DevBuf* b : alts) b->release();
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
@@ -1561,7 +1565,7 @@ int rdr_generate_brdf_lut(rdr_ctx* c, uint32_t size, uint32_t samples) {
     DevBuf d_trig;
     HIP_TRY(d_trig.ensure(trig.size() * 4));
     HIP_TRY(hipMemcpyAsync(d_trig.p, trig.data(), trig.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c->d_lut.ensure((size_t)size * size * 4));
+    HIP_TRY(c->d_lut.ensure((size_t)size * size * 4 + 16));  // spare words: the shading kernels read texel pairs
     launch_brdf_lut(c->stream, c->d_lut.as<uint32_t>(), (int)size, (int)samples, d_trig.as<float>());
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
@@ -1590,7 +1594,7 @@ int rdr_set_brdf_lut(rdr_ctx* c, const uint8_t* px, uint32_t w, uint32_t h, uint
         for (int k = 0; k < 3; k++) rgba[i * 4 + k] = px[i * channels + k];
         rgba[i * 4 + 3] = channels == 4 ? px[i * 4 + 3] : 255;
     }
-    HIP_TRY(c->d_lut.ensure(rgba.size()));
+    HIP_TRY(c->d_lut.ensure(rgba.size() + 16));  // spare words: the shading kernels read texel pairs
     HIP_TRY(hipMemcpy(c->d_lut.p, rgba.data(), rgba.size(), hipMemcpyHostToDevice));
     c->lut_w = w; c->lut_h = h;
     return RDR_OK;
@@ -1632,6 +1636,8 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         std::swap(c->d_batch_tables, o.batch_tables); std::swap(c->d_frame, o.frame); std::swap(c->d_shade_tris, o.shade_tris);
         std::swap(c->d_recs, o.recs); std::swap(c->d_tile_start, o.tile_start); std::swap(c->d_depth, o.depth); std::swap(c->d_vis, o.vis);
         std::swap(c->d_dir_shadow, o.dir_shadow); std::swap(c->d_hdr, o.hdr);
+        // the 4x rasteriser of this frame fills the fragment lists while the previous frame is still shaded from its own
+        std::swap(c->d_ofrag_recs, o.ofrag_recs); std::swap(c->d_pixel_state, o.pixel_state); std::swap(c->d_tile_first, o.tile_first);
         for (int k = 0; k < 2; k++) { std::swap(c->d_keys[k], o.keys[k]); std::swap(c->d_vals[k], o.vals[k]); }
     }
     HIP_TRY(c->d_depth.ensure(n * S * 4));
@@ -1750,8 +1756,22 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
                                frame_counters(c), tris_blend);
         return RDR_OK;
     };
+    // The fragment lists of the opaque pass: filled by the 4x rasteriser from the tiles' samples while they are in LDS
+    // (RDR_FUSED_CLASSIFY=0: by k_frag_classify from the visibility image, a measurement aid).
+    const size_t frag_slots = shade_frag_slots(W, H, (int)S);
+    const uint32_t n_screen_tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
+    if (frag_slots >= (1ull << 32)) return fail(c, RDR_ERR_CAPACITY, "render_frame: the image has more than 2^32 samples");
+    HIP_TRY(c->d_ofrag_recs.ensure(frag_slots * 8));
+    HIP_TRY(c->d_ofrag_cols.ensure(frag_slots * 8));
+    HIP_TRY(c->d_pixel_state.ensure((size_t)n_screen_tiles * 256 * 4));
+    HIP_TRY(c->d_tile_first.ensure((size_t)n_screen_tiles * 4));
+    uint32_t* const list_count = frame_counters(c) + RDR_COUNTER_LISTS / 4u;
+    const FragLists L = make_frag_lists(W, H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(), c->d_tile_first.as<uint32_t>(),
+                                        list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
+    bool fused_classify = S == 4;
+    if (const char* e = getenv("RDR_FUSED_CLASSIFY")) fused_classify = fused_classify && atoi(e) != 0;
     int cur = 0;
-    RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup));
+    RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup, fused_classify ? &L : nullptr));
     if (blend_view) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     const uint32_t blend_tile_base = blend_view ? b.views.back().tile_base : 0u;
@@ -1762,17 +1782,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     // behind the previous frame's shading and tail
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev[1], 0));
     {
-        const size_t slots = shade_frag_slots(W, H, (int)S);
-        const uint32_t n_tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
-        if (slots >= (1ull << 32)) return fail(c, RDR_ERR_CAPACITY, "render_frame: the image has more than 2^32 samples");
-        HIP_TRY(c->d_ofrag_recs.ensure(slots * 8));
-        HIP_TRY(c->d_ofrag_cols.ensure(slots * 8));
-        HIP_TRY(c->d_pixel_state.ensure((size_t)n_tiles * 256 * 4));
-        HIP_TRY(c->d_tile_first.ensure((size_t)n_tiles * 4));
-        uint32_t* list_count = frame_counters(c) + RDR_COUNTER_LISTS / 4u;
-        const FragLists L = make_frag_lists(W, H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(), c->d_tile_first.as<uint32_t>(),
-                                            list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
-        launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_vis.as<uint32_t>(), L);
+        if (!fused_classify) launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_vis.as<uint32_t>(), L);
         HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
         launch_shade_frags(c->stream2, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, L, c->shade_blocks);
         HIP_TRY(hipEventRecord(c->ev[7], c->stream2));
