@@ -772,7 +772,11 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
                     u = n_unique;
 #pragma unroll
                     for (int k = S - 1; k >= 0; k--) if ((uint32_t)k < n_unique && cls_ids[q][k] == vid[s]) u = (uint32_t)k;
-                    if (u == n_unique) { cls_ids[q][n_unique] = vid[s]; n_unique++; }
+                    if (u == n_unique) {  // (written without a variable index: the ids stay in registers)
+#pragma unroll
+                        for (int k = 0; k < S; k++) if ((uint32_t)k == n_unique) cls_ids[q][k] = vid[s];
+                        n_unique++;
+                    }
                 }
                 st |= u << (16 + 4 * s);
             }

@@ -238,6 +238,8 @@ struct rdr_ctx {
     // GPU's issue slots (their tiles mostly wait): the 4x one runs on a second stream beside the other.
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_raster1 = nullptr;  // the rasteriser launches of `stream` of the last batch are done
+    bool raster_side = false;         // ... and its 4x rasteriser ran on stream3 (ev_join)
     // Geometry and shading of consecutive frames overlap: `stream` carries the geometry phase of a frame (set-up, binning,
     // sort, rasterisers; `stream3` takes the 4x rasteriser beside the shadow-view one), `stream2` its shading, blended
     // pass and tail. What the geometry phase writes and the shading reads exists twice (`alt` holds the set of the
@@ -829,6 +831,10 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
         launch_shadow_cube_border(c->stream, c->d_point_shadow.as<float>(), (int)c->settings.point_shadow_map_resolution, c->point_cubes_in_use);
         c->point_borders_stale = false;
     }
+    // what comes behind the batch on another stream waits for these two itself: one hop from the rasteriser that ends
+    // last instead of two (stream3 -> stream -> the other stream, some ten microseconds each)
+    HIP_TRY(hipEventRecord(c->ev_raster1, c->stream));
+    c->raster_side = side;
     if (side) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     HIP_TRY(hipGetLastError());
     return RDR_OK;
@@ -1119,6 +1125,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     ok = ok && hipStreamCreate(&c->stream2) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_raster1, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreate(&c->stream3) == hipSuccess && hipStreamCreate(&c->stream4) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_shaded[i], hipEventDisableTiming) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
@@ -1178,6 +1185,7 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_raster1) (void)hipEventDestroy(c->ev_raster1);
     for (int i = 0; i < 2; i++) if (c->ev_shaded[i]) (void)hipEventDestroy(c->ev_shaded[i]);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -1778,9 +1786,10 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
 
     // ---- opaque shading + skybox
     if (S == 4 && have_blend) HIP_TRY(c->d_samples.ensure(n * 4 * 8));
-    // from here on the frame runs on the shading stream, behind its own geometry phase (ev[1]) and, in stream order,
+    // from here on the frame runs on the shading stream, behind the tile rasterisers of its own geometry phase and, in stream order,
     // behind the previous frame's shading and tail
-    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev[1], 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_raster1, 0));
+    if (c->raster_side) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_join, 0));
     {
         if (!fused_classify) launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_vis.as<uint32_t>(), L);
         HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
