@@ -272,3 +272,30 @@ def test_blended_pass_in_bounded_memory(orc_capi, hip_capi, msaa, monkeypatch):
     # a second frame on the same context (buffers are reused, counters restart)
     out_g2, _ = r_groups.render_frame(**frame)
     assert np.array_equal(out_g2, out_g)
+
+
+@pytest.mark.parametrize("size", [(320, 180), (333, 207), (2050, 1030)])
+def test_fragment_lists_from_the_rasteriser_or_from_the_visibility_image(hip_capi, monkeypatch, size):
+    """The fragment lists of the opaque pass are built inside the 4x rasteriser (from the tile's samples in LDS) or,
+    with RDR_FUSED_CLASSIFY=0, by a separate pass over the visibility image. Both must give the same frame bit for
+    bit (HDR image, 8-bit frame, depth, visibility), at sizes with partial tiles and with rectangles of unequal tile
+    counts, over several frames in a row (the lists exist once per frame slot)."""
+    from renderer_amd.api import Renderer
+    W, H = size
+    frames = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RDR_FUSED_CLASSIFY", mode)
+        r = Renderer(hip_capi, W, H, hp.default_settings(**hp.small_settings(4)))
+        scenes.small_scene(r)
+        got = []
+        for k in range(3):
+            r.set_camera(position=(0.3 * k - 0.4, 1.3, 4.0 - 0.3 * k), euler=(-0.12, 0.07 * k, 0.0))
+            out, avg = r.render_frame(exposure_mode=1, temporal_luminance=0.5)
+            got.append((out.copy(), r.read_hdr(), r.read_depth(), r.read_visibility(), avg))
+        frames[mode] = got
+        r.close()
+    for k in range(3):
+        a, b = frames["1"][k], frames["0"][k]
+        for x, y, what in zip(a[:4], b[:4], ("frame", "hdr", "depth", "visibility")):
+            assert np.array_equal(x, y), f"{what} of frame {k} differs between the two ways of building the lists"
+        assert a[4] == b[4]
