@@ -7,18 +7,18 @@
 // env.frag:10-17; pass order and blend state Renderer/VulkanRenderer.cpp:1043-1065,
 // :862-866.
 //
-// Structure of the opaque pass (k_shade_setup -> k_shade_opaque):
+// Structure of the opaque pass (k_shade_setup -> fragment lists -> k_shade_frags -> k_frag_resolve):
 //  * k_shade_setup, one thread per main-view triangle that survived set-up:
 //    runs basic.vert for its three vertices once and stores the outputs plus
 //    the perspective-correct barycentric planes in a 384-byte DShadeTri, so a
 //    fragment never re-transforms vertices.
-//  * k_shade_opaque, one 256-thread block per 16x16 tile. With 4x MSAA a pixel
-//    is shaded once per DISTINCT triangle among its samples; looping over
-//    those inside the pixel's lane leaves most lanes idle on the 2nd..4th
-//    pass. Instead the block compacts its (pixel, triangle) fragments into a
-//    list in LDS (ballot prefix sums), shades the list densely - every lane a
-//    fragment - parks the RGBA16F results in LDS, and each pixel then
-//    resolves its samples from there.
+//  * With 4x MSAA a pixel is shaded once per DISTINCT triangle among its
+//    samples. Those (triangle, pixel) fragments of the whole frame are
+//    collected in lists (by the 4x rasteriser, kernels_raster.hip, or by
+//    k_frag_classify from the visibility image), k_shade_frags shades the
+//    lists densely - every lane a fragment, no tile, no barrier - and
+//    k_frag_resolve turns the fragment colours into pixels (described in front
+//    of the three kernels below).
 // All scene data is read in place from HBM (geometry arena, RGBA8 mip chains,
 // packed-float cubes, D32F shadow arrays).
 //
