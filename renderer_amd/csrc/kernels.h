@@ -84,6 +84,8 @@ FragLists make_frag_lists(uint32_t W, uint32_t H, int samples, void* frag_recs, 
                           uint32_t* list_count, uint32_t* list_claim);
 void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const uint32_t* vis, const FragLists& L);
 void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks);
+// the visibility image rebuilt from the lists (frames whose rasteriser built the lists do not store it)
+void launch_vis_from_lists(hipStream_t s, int samples, const FragLists& L, uint32_t W, uint32_t H, uint32_t* vis);
 void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const FragLists& L, void* hdr, void* samples_out, const uint32_t* blend_start,
                          const uint32_t* blend_end, uint32_t W, uint32_t H);
 // blended pass: fragment list slots are handed out in runs of RDR_FRAG_RUN; `capacity` slots exist (see blend_capacity);

@@ -784,6 +784,24 @@ __global__ void __launch_bounds__(256) k_frag_resolve(const DFrame* __restrict__
     }
 }
 
+// The visibility image (triangle id per sample, 0xFFFFFFFF where nothing covers) from the fragment lists: what a frame
+// whose lists were built inside the rasteriser hands to rdr_read_visibility instead of storing the image every frame.
+template <int S>
+__global__ void __launch_bounds__(256) k_vis_from_lists(FragLists L, uint32_t W, uint32_t H, uint32_t* __restrict__ vis) {
+    const uint32_t tiles_x = (W + RDR_TILE - 1) / RDR_TILE;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t px = (tile % tiles_x) * RDR_TILE + (threadIdx.x & 15u), py = (tile / tiles_x) * RDR_TILE + (threadIdx.x >> 4);
+    if (px >= W || py >= H) return;
+    const size_t plane_px = (size_t)W * H, o = (size_t)py * W + px;
+    const uint32_t state = L.pixel_state[(size_t)tile * 256u + threadIdx.x];
+    const uint32_t first = L.tile_first[tile] + (state & 0xFFFFu);
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const uint32_t slot = (state >> (16 + 4 * s)) & 15u;
+        vis[s * plane_px + o] = slot == 15u ? 0xFFFFFFFFu : L.recs[first + slot].x;
+    }
+}
+
 #define BLEND_CHUNK 64
 #define BLEND_NONE 0xFFFFFFFFu
 
@@ -1040,6 +1058,11 @@ void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const ui
 }
 void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks) {
     hipLaunchKernelGGL(k_shade_frags, dim3(blocks), dim3(256), 0, s, fr, lights, tris, L);
+}
+void launch_vis_from_lists(hipStream_t s, int samples, const FragLists& L, uint32_t W, uint32_t H, uint32_t* vis) {
+    const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
+    if (samples == 1) hipLaunchKernelGGL(k_vis_from_lists<1>, dim3(tiles), dim3(256), 0, s, L, W, H, vis);
+    else hipLaunchKernelGGL(k_vis_from_lists<4>, dim3(tiles), dim3(256), 0, s, L, W, H, vis);
 }
 void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const FragLists& L, void* hdr, void* samples_out, const uint32_t* blend_start,
                          const uint32_t* blend_end, uint32_t W, uint32_t H) {

@@ -206,6 +206,7 @@ struct rdr_ctx {
     DevBuf d_frags, d_frag_col, d_frag_head, d_tile_slots;
     // opaque pass: fragment records and colours (one list per screen rectangle), per-pixel state, first fragment per tile
     DevBuf d_ofrag_recs, d_ofrag_cols, d_pixel_state, d_tile_first;
+    bool vis_in_lists = false;  // the last frame's visibility lives in its fragment lists (rdr_read_visibility unpacks it)
     uint32_t shade_blocks = 1024;  // grid of the fragment shading kernel: four 256-thread blocks per compute unit
     uint64_t blend_budget_slots = 48ull << 20;  // fragment-list slots (32 B each) a frame may use at once; RDR_BLEND_BUDGET_SLOTS overrides (tests)  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
 
@@ -1649,7 +1650,13 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         for (int k = 0; k < 2; k++) { std::swap(c->d_keys[k], o.keys[k]); std::swap(c->d_vals[k], o.vals[k]); }
     }
     HIP_TRY(c->d_depth.ensure(n * S * 4));
-    HIP_TRY(c->d_vis.ensure(n * S * 4));
+    // The fragment lists of the opaque pass are filled by the 4x rasteriser from the tiles' samples while they are in
+    // LDS (RDR_FUSED_CLASSIFY=0: by k_frag_classify from the visibility image, a measurement aid). The rasteriser then
+    // does not store the visibility image at all: rdr_read_visibility rebuilds it from the lists.
+    bool fused_classify = S == 4;
+    if (const char* e = getenv("RDR_FUSED_CLASSIFY")) fused_classify = fused_classify && atoi(e) != 0;
+    if (!fused_classify) HIP_TRY(c->d_vis.ensure(n * S * 4));
+    c->vis_in_lists = fused_classify;
     HIP_TRY(c->d_hdr.ensure(n * 8));
     c->stats = rdr_frame_stats{};
     c->stats.frame_index = ++c->frames;
@@ -1676,7 +1683,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     std::vector<uint32_t> opaque, non_opaque;
     for (uint32_t p = 0; p < c->prims.size(); p++) (c->prims[p].mat.alpha_mode == RDR_ALPHA_OPAQUE ? opaque : non_opaque).push_back(p);
     const uint32_t main_view = (uint32_t)b.views.size();
-    b.views.push_back(make_view(c->d_depth.as<float>(), c->d_vis.as<uint32_t>(), W, H, S, 2, 0));
+    b.views.push_back(make_view(c->d_depth.as<float>(), fused_classify ? nullptr : c->d_vis.as<uint32_t>(), W, H, S, 2, 0));
     // the order of these two lists shows: visibility ids follow it, the earlier draw keeps a depth tie, blending is
     // back to front (VulkanRenderer.cpp:945-963)
     add_view_draws(c, b, CAND_OPAQUE, opaque, viewproj, cam_pos, SORT_FRONT_TO_BACK, main_view, false);
@@ -1764,8 +1771,6 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
                                frame_counters(c), tris_blend);
         return RDR_OK;
     };
-    // The fragment lists of the opaque pass: filled by the 4x rasteriser from the tiles' samples while they are in LDS
-    // (RDR_FUSED_CLASSIFY=0: by k_frag_classify from the visibility image, a measurement aid).
     const size_t frag_slots = shade_frag_slots(W, H, (int)S);
     const uint32_t n_screen_tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
     if (frag_slots >= (1ull << 32)) return fail(c, RDR_ERR_CAPACITY, "render_frame: the image has more than 2^32 samples");
@@ -1776,8 +1781,6 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     uint32_t* const list_count = frame_counters(c) + RDR_COUNTER_LISTS / 4u;
     const FragLists L = make_frag_lists(W, H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(), c->d_tile_first.as<uint32_t>(),
                                         list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
-    bool fused_classify = S == 4;
-    if (const char* e = getenv("RDR_FUSED_CLASSIFY")) fused_classify = fused_classify && atoi(e) != 0;
     int cur = 0;
     RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup, fused_classify ? &L : nullptr));
     if (blend_view) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
@@ -1958,6 +1961,16 @@ int rdr_read_depth(rdr_ctx* c, float* out) {
 }
 int rdr_read_visibility(rdr_ctx* c, uint32_t* out) {
     if (!c || !out || !c->have_frame) return fail(c, RDR_ERR_INVALID, "read_visibility: no frame");
+    if (c->vis_in_lists) {
+        const uint32_t S = c->settings.msaa;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(c->d_vis.ensure((size_t)c->W * c->H * S * 4));
+        const FragLists L = make_frag_lists(c->W, c->H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(),
+                                            c->d_tile_first.as<uint32_t>(), nullptr, nullptr);
+        HIP_TRY(hipStreamSynchronize(c->stream3));  // the rasteriser that filled the lists
+        launch_vis_from_lists(c->stream2, (int)S, L, c->W, c->H, c->d_vis.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
     return read_back(c, out, c->d_vis.p, (size_t)c->W * c->H * c->settings.msaa * 4);
 }
 int rdr_read_directional_shadow(rdr_ctx* c, uint32_t index, float* out) {
