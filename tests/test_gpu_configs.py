@@ -215,3 +215,22 @@ def test_config3_animation_batch_1080p(hip_capi):
         assert np.array_equal(img, runs[0][0][k]), f"frame {k} rendered alone differs from the batch"
         assert avg == runs[0][1][k]
     r2.close()
+
+
+def test_benchmark_frame_against_the_checker_at_full_size(orc_capi, hip_capi):
+    """The exact frame bench.py times (Sponza-class scene at full detail, 1024^2 textures, 3840x2160, 4x MSAA, 4
+    cascades of 2048^2, 16 point lights of which 8 cast shadows, IBL, bloom + tonemap), HIP library against the CPU
+    checker: depth, coverage, cascades and point-light faces bit for bit, the 8-bit frame within 1/255 and 45 dB."""
+    W, H = 3840, 2160
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, msaa=4)
+    scenes.sponza_like(ro)
+    scenes.sponza_like(rh)
+    for r in (ro, rh):  # frame 0 of the benchmark's camera path
+        r.set_camera(position=(-11.0, 2.2, 0.6), euler=(-0.05, -1.45, 0.0))
+    compare_frame(ro, rh)
+    for slot in range(8):
+        for face in (0, 3, 5):
+            assert np.array_equal(ro.read_point_shadow(slot, face), rh.read_point_shadow(slot, face)), (slot, face)
+    so, sh = ro.frame_stats(), rh.frame_stats()
+    assert (so.triangle_instances, so.triangles_binned, so.views) == (sh.triangle_instances, sh.triangles_binned, sh.views)
+    ro.close(); rh.close()
