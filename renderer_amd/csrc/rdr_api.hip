@@ -241,6 +241,7 @@ struct rdr_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_raster1 = nullptr;  // the rasteriser launches of `stream` of the last batch are done
     bool raster_side = false;         // ... and its 4x rasteriser ran on stream3 (ev_join)
+    hipStream_t raster_stream = nullptr;  // stream the shadow-view rasteriser of the last batch was enqueued on
     // Geometry and shading of consecutive frames overlap: `stream` carries the geometry phase of a frame (set-up, binning,
     // sort, rasterisers; `stream3` takes the 4x rasteriser beside the shadow-view one), `stream2` its shading, blended
     // pass and tail. What the geometry phase writes and the shading reads exists twice (`alt` holds the set of the
@@ -784,7 +785,12 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
 // `after_scan`, if given, runs once set-up and the pair scan are enqueued and before the host waits for the pair
 // count: work enqueued there keeps the GPU busy while the host sizes the pair buffers.
 // `classify`: fragment lists the 4x rasteriser fills for the opaque pass (the frame's main batch), or null.
-int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::function<int()>& after_scan = nullptr, const FragLists* classify = nullptr) {
+// `main_batch`: the frame's own batch. Its shadow-view rasteriser goes to the shading stream (in front of the frame's
+// shading, which needs it, and behind the previous frame's, which reads the point-light maps it writes) instead of
+// following the front end on `stream`: `stream` is then free for the front end of the next frame, which the host
+// enqueues while this frame is rasterised, and does not queue behind the rasterisers.
+int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::function<int()>& after_scan = nullptr, const FragLists* classify = nullptr,
+                 bool main_batch = false) {
     if (b.views.empty()) return RDR_OK;
     uint32_t n_tiles = 0;
     int cur = 0;
@@ -802,7 +808,11 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
         if (r.first_tile == 0xFFFFFFFFu) { r.first_tile = v.tile_base; r.first_view = vi; }
         r.end_tile = v.tile_base + v.tiles_x * v.tiles_y;
     }
-    HIP_TRY(hipEventRecord(c->ev[8], c->stream));
+    hipStream_t rs = (main_batch && !getenv("RDR_RASTER_ON_FRONT_END_STREAM")) ? c->stream2 : c->stream;
+    c->raster_stream = rs;
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));  // the sorted tile lists (and everything else the front end leaves) are there
+    if (rs != c->stream) HIP_TRY(hipStreamWaitEvent(rs, c->ev_fork, 0));
+    HIP_TRY(hipEventRecord(c->ev[8], rs));
     const RasterRange none = {0xFFFFFFFFu, 0u, 0u};
     auto launch = [&](hipStream_t st, const RasterRange& s1, const RasterRange& s4) {
         launch_raster(st, b.views.data(), (uint32_t)b.views.size(), c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
@@ -813,30 +823,29 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
     // RDR_SERIAL_RASTER: measurement aid, the rasterisers one after the other so that a profile shows each alone
     const bool side = rr[2].first_tile < rr[2].end_tile && (rr[0].first_tile < rr[0].end_tile || rr[1].first_tile < rr[1].end_tile) && !getenv("RDR_SERIAL_RASTER");
     if (side) {
-        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
         launch(c->stream3, none, rr[2]);
         HIP_TRY(hipEventRecord(c->ev_join, c->stream3));
     } else {
-        launch(c->stream, none, rr[2]);
+        launch(rs, none, rr[2]);
     }
-    launch(c->stream, rr[0], none);
+    launch(rs, rr[0], none);
     if (rr[1].first_tile < rr[1].end_tile) {
         // the point-light shadow maps exist once: the previous frame's shading may still be reading them
-        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[c->slot ^ 1], 0));
-        launch(c->stream, rr[1], none);
+        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(rs, c->ev_shaded[c->slot ^ 1], 0));
+        launch(rs, rr[1], none);
     }
     if (c->point_borders_stale && c->point_cubes_in_use) {
         // behind every rasteriser launch of this stream that writes point-light faces (static maps were copied in before)
-        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[c->slot ^ 1], 0));
-        launch_shadow_cube_border(c->stream, c->d_point_shadow.as<float>(), (int)c->settings.point_shadow_map_resolution, c->point_cubes_in_use);
+        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(rs, c->ev_shaded[c->slot ^ 1], 0));
+        launch_shadow_cube_border(rs, c->d_point_shadow.as<float>(), (int)c->settings.point_shadow_map_resolution, c->point_cubes_in_use);
         c->point_borders_stale = false;
     }
     // what comes behind the batch on another stream waits for these two itself: one hop from the rasteriser that ends
     // last instead of two (stream3 -> stream -> the other stream, some ten microseconds each)
-    HIP_TRY(hipEventRecord(c->ev_raster1, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_raster1, rs));
     c->raster_side = side;
-    if (side) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (side) HIP_TRY(hipStreamWaitEvent(rs, c->ev_join, 0));
     HIP_TRY(hipGetLastError());
     return RDR_OK;
 }
@@ -1782,9 +1791,9 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     const FragLists L = make_frag_lists(W, H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(), c->d_tile_first.as<uint32_t>(),
                                         list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
     int cur = 0;
-    RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup, fused_classify ? &L : nullptr));
+    RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup, fused_classify ? &L : nullptr, true));
     if (blend_view) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->raster_stream ? c->raster_stream : c->stream));
     const uint32_t blend_tile_base = blend_view ? b.views.back().tile_base : 0u;
 
     // ---- opaque shading + skybox
