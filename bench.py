@@ -150,7 +150,7 @@ def main():
     # it to finish (a communication kernel enqueued beside the shading kernel gets few wave slots and runs many times
     # longer than alone; the staging tensors are 33 MB each, rank 0 holds world x 4 more to receive into)
     from renderer_amd.sharding import FrameSharder
-    sharder = FrameSharder(r, dist=dist, device=f"cuda:{local_rank}", depth=4 if world > 1 else 2)
+    sharder = FrameSharder(r, dist=dist, device=f"cuda:{local_rank}", depth=4 if world > 1 else 3)
     frame_params = dict(exposure_mode=1, temporal_luminance=0.5)
     acc = {"shade_kernel": 0.0, "raster_kernel": 0.0, "geometry": 0.0, "shade": 0.0, "bloom": 0.0, "tonemap": 0.0, "total": 0.0, "host": 0.0}
     last_stats = [None]

@@ -309,15 +309,23 @@ int rdr_set_exposure_bias(rdr_ctx* ctx, float exposure_bias, float gamma);
  * NULL skips the copy.
  *
  * Frames in flight (the reference keeps two, VulkanRenderer.cpp:1013-1030): with a device destination the next
- * rdr_render_frame may be called without rdr_synchronize in between. It builds and enqueues its shadow and
- * geometry work while the GPU finishes the previous frame, and by the time it returns the previous frame is
- * complete: its image is in its destination and rdr_get_frame_stats describes it (frame_index tells which
- * frame the numbers belong to). rdr_synchronize waits for everything enqueued; after it rdr_get_frame_stats
- * describes the last frame. Results are handed over at those two points only (never by rdr_get_frame_stats
- * itself), so which frame the statistics describe does not depend on timing. */
+ * rdr_render_frame may be called without rdr_synchronize in between. It builds and enqueues its frame while the GPU
+ * finishes the previous one, and by the time it returns the previous frame is complete: its image is in its
+ * destination and rdr_get_frame_stats describes it (frame_index tells which frame the numbers belong to). With
+ * RDR_FRAMES_IN_FLIGHT=3 in the environment of rdr_create three frames are in flight and it is the frame two calls
+ * back that is complete when a call returns; a destination buffer must then not be handed to another frame before the
+ * frame it was given to is complete (three destinations in rotation, or rdr_wait_frame). rdr_wait_frame waits for
+ * one frame, rdr_synchronize for everything enqueued; after either rdr_get_frame_stats describes the newest complete
+ * frame. Results are handed over at those points only (never by rdr_get_frame_stats itself), so which frame the
+ * statistics describe does not depend on timing. */
 int rdr_render_frame(rdr_ctx* ctx, const rdr_frame_params* params, uint8_t* out_rgba8, int out_is_device,
                      float* out_avg_log_luminance);
 int rdr_synchronize(rdr_ctx* ctx);
+/* Waits until the frame with this frame_index (rdr_frame_stats::frame_index, counted from 1) is complete and hands
+ * over the results of every frame up to and including it, oldest first; rdr_get_frame_stats then describes it.
+ * Returns at once for a frame whose results were handed over before; RDR_ERR_INVALID for a frame not yet enqueued.
+ * (The reference waits on the fence of a frame in flight the same way, VulkanRenderer.cpp:1016-1019.) */
+int rdr_wait_frame(rdr_ctx* ctx, uint64_t frame_index);
 int rdr_get_frame_stats(rdr_ctx* ctx, rdr_frame_stats* out);
 
 /* ---- debug read-backs (needed for bit-exact parity tests) -------------- */

@@ -703,6 +703,11 @@ int orc_synchronize(rdr_ctx* c) {
     if (c && c->stats_deferred) { c->done_stats = c->stats; c->stats_deferred = false; }
     return RDR_OK;
 }
+int orc_wait_frame(rdr_ctx* c, uint64_t frame_index) {
+    if (!c || frame_index > c->stats.frame_index) return RDR_ERR_INVALID;
+    if (c->stats_deferred && c->stats.frame_index <= frame_index) { c->done_stats = c->stats; c->stats_deferred = false; }
+    return RDR_OK;
+}
 int orc_get_frame_stats(rdr_ctx* c, rdr_frame_stats* out) { if (!c || !out) return RDR_ERR_INVALID; *out = c->done_stats; return RDR_OK; }
 
 int orc_read_depth(rdr_ctx* c, float* out) { if (!c || !out || c->depth.empty()) return RDR_ERR_INVALID; std::memcpy(out, c->depth.data(), c->depth.size() * 4); return RDR_OK; }

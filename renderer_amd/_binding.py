@@ -115,6 +115,7 @@ SIGNATURES = {
     "set_exposure_bias": (C.c_int, [_VP, C.c_float, C.c_float]),
     "render_frame": (C.c_int, [_VP, C.POINTER(FrameParams), _VP, C.c_int, _FP]),
     "synchronize": (C.c_int, [_VP]),
+    "wait_frame": (C.c_int, [_VP, C.c_uint64]),
     "get_frame_stats": (C.c_int, [_VP, C.POINTER(FrameStats)]),
     "read_depth": (C.c_int, [_VP, _FP]),
     "read_visibility": (C.c_int, [_VP, _U32P]),

@@ -237,6 +237,10 @@ class Renderer:
     def synchronize(self):
         self._check(self.api.synchronize(self._ctx), "synchronize")
 
+    def wait_frame(self, frame_index):
+        """Waits for the frame with that index (frame_stats().frame_index counts them from 1); frame_stats() then describes it."""
+        self._check(self.api.wait_frame(self._ctx, int(frame_index)), "wait_frame")
+
     def frame_stats(self):
         s = B.FrameStats()
         self._check(self.api.get_frame_stats(self._ctx, C.byref(s)), "get_frame_stats")

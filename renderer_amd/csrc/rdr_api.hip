@@ -37,8 +37,9 @@ namespace {
 #define RDR_COUNTER_SLOT_BYTES (RDR_COUNTER_BYTES + (RDR_FRAG_SEGS + 8u) * RDR_FRAG_CTR_STRIDE * 4u)  // what a frame zeroes
 #define RDR_COUNTER_LUM 4u  // word of the scalar counters that the luminance reduction writes its result to
 #define RDR_COUNTER_FRAGS 5u  // word the blended pass counts its fragment-list slots in (zero after the frame's fill)
-#define RDR_READ_MID (2u * RDR_COUNTER_BYTES)
-#define RDR_READ_BYTES (3u * RDR_COUNTER_BYTES)
+#define RDR_FRAME_SLOTS 3  // frames that can be in flight: each has its own buffer set, events, counters and read-back block
+#define RDR_READ_MID ((unsigned)RDR_FRAME_SLOTS * RDR_COUNTER_BYTES)
+#define RDR_READ_BYTES ((unsigned)(RDR_FRAME_SLOTS + 1) * RDR_COUNTER_BYTES)
 
 struct DevBuf {
     void* p = nullptr;
@@ -217,22 +218,23 @@ struct rdr_ctx {
     // over the moving primitives.
     uint64_t geometry_version = 1, lights_version = 1;
     struct ShadowKey { bool valid = false; uint64_t geometry = 0, lights = 0, hash = 0; };
-    ShadowKey cascades_key[2], point_dynamic_key;
+    ShadowKey cascades_key[RDR_FRAME_SLOTS], point_dynamic_key;
     uint32_t views_reused = 0;          // shadow views of the frame being enqueued that were left as they are
     bool point_borders_stale = false;   // a face of a point-light cube was (or is about to be) re-rendered: the borders follow
     uint32_t point_cubes_in_use = 0;
     unsigned long long frame_pairs_before = 0;  // (triangle, tile) pairs of the batches of this frame binned so far
     double host_wait_s = 0.0;           // time the current rdr_render_frame call has spent blocked on the GPU
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
-    // Two frames can be in flight: a frame rendered into a device destination is only enqueued, and the next call builds
-    // and enqueues its first half while the GPU still works on this one. Each keeps its own events and its own block
-    // of the pinned read-back area until its results are picked up (harvest()).
+    // Two frames are in flight, three on request: a frame rendered into a device destination is only enqueued, and the
+    // next call (the next two, with `lag` = 2) builds and enqueues its own while the GPU still works on this one. Each
+    // keeps its own events and its own block of the pinned read-back area until its results are picked up (harvest()).
     rdr_frame_stats stats{};       // host-side counters of the frame being enqueued
     rdr_frame_stats done_stats{};  // the newest frame whose results have been picked up: what rdr_get_frame_stats returns
-    struct PendingFrame { bool on = false; rdr_frame_stats host{}; } pending[2];
+    struct PendingFrame { bool on = false; rdr_frame_stats host{}; } pending[RDR_FRAME_SLOTS];
     uint64_t frames = 0;           // frames enqueued so far
-    int slot = 0;                  // frames & 1 of the frame being enqueued
-    hipEvent_t ev_sets[2][10] = {};
+    int slot = 0;                  // frame slot of the frame being enqueued (frames enqueued before it, modulo RDR_FRAME_SLOTS)
+    int lag = 1;                   // a call returns once the frame `lag` calls back has finished and been picked up (RDR_FRAMES_IN_FLIGHT - 1)
+    hipEvent_t ev_sets[RDR_FRAME_SLOTS][10] = {};
     hipEvent_t* ev = ev_sets[0];   // the events of the frame being enqueued
     hipEvent_t ev_pairs = nullptr;  // the pair count of the batch being binned has reached the host
     // The two tile rasterisers of a batch (single-sampled shadow views, 4x view) are independent and neither fills the
@@ -250,8 +252,8 @@ struct rdr_ctx {
     // their rasteriser launch waits for the previous frame's shading (ev_shaded).
     hipStream_t stream3 = nullptr;
     hipStream_t stream4 = nullptr;  // the tail of a frame (bloom chain, tonemap, luminance, read-backs), beside the next frame's shading
-    hipEvent_t ev_shaded[2] = {nullptr, nullptr};
-    struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr, ofrag_recs, pixel_state, tile_first; } alt;
+    hipEvent_t ev_shaded[RDR_FRAME_SLOTS] = {};
+    struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr, ofrag_recs, pixel_state, tile_first; } alt[RDR_FRAME_SLOTS - 1];
     PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
     unsigned char* noalloc_scratch = nullptr;  // address of `scratch` on this context's device
 };
@@ -269,7 +271,7 @@ int hip_fail(rdr_ctx* c, const char* what, hipError_t e) {
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(c, #expr, e_); } while (0)
 #define RDR_TRY(expr) do { int r_ = (expr); if (r_ != RDR_OK) return r_; } while (0)
 
-// counters block of the frame being enqueued (each of the two frame slots has its own: the tail of a frame still
+// counters block of the frame being enqueued (each frame slot has its own: the tail of a frame still
 // writes its block while the next frame has cleared and is filling the other)
 uint32_t* frame_counters(const rdr_ctx* c) { return (uint32_t*)(c->d_counters.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_SLOT_BYTES); }
 
@@ -785,6 +787,8 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
 // `after_scan`, if given, runs once set-up and the pair scan are enqueued and before the host waits for the pair
 // count: work enqueued there keeps the GPU busy while the host sizes the pair buffers.
 // `classify`: fragment lists the 4x rasteriser fills for the opaque pass (the frame's main batch), or null.
+int prev_slot(const rdr_ctx* c) { return (c->slot + RDR_FRAME_SLOTS - 1) % RDR_FRAME_SLOTS; }
+
 // `main_batch`: the frame's own batch. Its shadow-view rasteriser goes to the shading stream (in front of the frame's
 // shading, which needs it, and behind the previous frame's, which reads the point-light maps it writes) instead of
 // following the front end on `stream`: `stream` is then free for the front end of the next frame, which the host
@@ -832,12 +836,12 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
     launch(rs, rr[0], none);
     if (rr[1].first_tile < rr[1].end_tile) {
         // the point-light shadow maps exist once: the previous frame's shading may still be reading them
-        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(rs, c->ev_shaded[c->slot ^ 1], 0));
+        if (c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(rs, c->ev_shaded[prev_slot(c)], 0));
         launch(rs, rr[1], none);
     }
     if (c->point_borders_stale && c->point_cubes_in_use) {
         // behind every rasteriser launch of this stream that writes point-light faces (static maps were copied in before)
-        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(rs, c->ev_shaded[c->slot ^ 1], 0));
+        if (c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(rs, c->ev_shaded[prev_slot(c)], 0));
         launch_shadow_cube_border(rs, c->d_point_shadow.as<float>(), (int)c->settings.point_shadow_map_resolution, c->point_cubes_in_use);
         c->point_borders_stale = false;
     }
@@ -932,7 +936,7 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
     }
     if (!sb.views.empty()) {
         RDR_TRY(raster_batch(c, sb));
-        if (c->pending[c->slot ^ 1].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[c->slot ^ 1], 0));  // see raster_batch
+        if (c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[prev_slot(c)], 0));  // see raster_batch
         for (uint32_t i : refreshed) {
             const size_t off = (size_t)c->lights[i].slot * 6 * face_px;
             HIP_TRY(hipMemcpyAsync(c->d_point_shadow.as<float>() + off, c->d_point_static.as<float>() + off, 6 * face_px * 4,
@@ -1021,7 +1025,7 @@ int cascade_views(rdr_ctx* c, Batch& b) {
         eye[i] = split_pov.position;
     }
     // The reference draws every cascade every frame (VulkanRendererShadow.cpp:424). The array of this frame slot
-    // still holds the cascades of two frames ago: if nothing that goes into them has changed since (same matrices,
+    // still holds the cascades of RDR_FRAME_SLOTS frames ago: if nothing that goes into them has changed since (same matrices,
     // no mesh added or moved), they are what this frame would render, and are left alone.
     rdr_ctx::ShadowKey& key = c->cascades_key[c->slot];
     uint64_t h = hash_words(14695981039346656037ull, &levels, 4);
@@ -1130,14 +1134,14 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->shade_blocks = (uint32_t)cus * shade_frags_blocks_per_cu();
     }
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
-    for (int i = 0; i < 20 && ok; i++) ok = hipEventCreate(&c->ev_sets[i / 10][i % 10]) == hipSuccess;
+    for (int i = 0; i < 10 * RDR_FRAME_SLOTS && ok; i++) ok = hipEventCreate(&c->ev_sets[i / 10][i % 10]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_pairs, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreate(&c->stream2) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_raster1, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreate(&c->stream3) == hipSuccess && hipStreamCreate(&c->stream4) == hipSuccess;
-    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_shaded[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < RDR_FRAME_SLOTS && ok; i++) ok = hipEventCreateWithFlags(&c->ev_shaded[i], hipEventDisableTiming) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
     std::vector<float> tables(768);
     for (int i = 0; i < 256; i++) {
@@ -1146,12 +1150,15 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
         tables[512 + i] = (float)srgb_eotf(((double)i + 0.5) / 255.0);
     }
     ok = ok && c->d_tables.ensure(768 * 4) == hipSuccess && hipMemcpy(c->d_tables.p, tables.data(), 768 * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && c->d_counters.ensure(2 * RDR_COUNTER_SLOT_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, 2 * RDR_COUNTER_SLOT_BYTES) == hipSuccess;
+    ok = ok && c->d_counters.ensure(RDR_FRAME_SLOTS * RDR_COUNTER_SLOT_BYTES) == hipSuccess && hipMemset(c->d_counters.p, 0, RDR_FRAME_SLOTS * RDR_COUNTER_SLOT_BYTES) == hipSuccess;
     ok = ok && c->d_frame.ensure(sizeof(DFrame) + 64) == hipSuccess;
     // this device's copy of the no-allocation scratch array (the device is current: hipSetDevice above)
     ok = ok && hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch)) == hipSuccess && c->noalloc_scratch != nullptr;
     if (!ok) { rdr_destroy(c); return RDR_ERR_DEVICE; }
     if (const char* e = getenv("RDR_BLEND_BUDGET_SLOTS")) { const long long v = atoll(e); if (v > 0) c->blend_budget_slots = (uint64_t)v; }
+    // 2 or 3 frames in flight (2 by default: a frame's results are there one call later; 3 gave +1 % frames/s on the
+    // benchmark frame and a shading kernel 2 % longer for what runs beside it)
+    if (const char* e = getenv("RDR_FRAMES_IN_FLIGHT")) { const int v = atoi(e); if (v == 2 || v == 3) c->lag = v - 1; }
     // measurement aid: size of the fragment shading kernel's grid (a multiple of 8, one share per die)
     if (const char* e = getenv("RDR_SHADE_BLOCKS")) { const long v = atol(e); if (v >= 8 && v <= 65536) c->shade_blocks = (uint32_t)v & ~7u; }
     c->camera.type = 0;  // VulkanRenderer.h:117, VulkanRenderer.cpp:50
@@ -1185,18 +1192,19 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_counters, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
     for (DevBuf* b : bufs) b->release();
-    DevBuf* alts[] = {&c->alt.batch_tables, &c->alt.frame, &c->alt.shade_tris, &c->alt.recs, &c->alt.keys[0], &c->alt.keys[1], &c->alt.vals[0],
-                      &c->alt.vals[1], &c->alt.tile_start, &c->alt.depth, &c->alt.vis, &c->alt.dir_shadow, &c->alt.hdr, &c->alt.ofrag_recs,
-                      &c->alt.pixel_state, &c->alt.tile_first};
-    for (DevBuf* b : alts) b->release();
+    for (rdr_ctx::AltBuffers& a : c->alt) {
+        DevBuf* alts[] = {&a.batch_tables, &a.frame, &a.shade_tris, &a.recs, &a.keys[0], &a.keys[1], &a.vals[0], &a.vals[1], &a.tile_start, &a.depth, &a.vis,
+                          &a.dir_shadow, &a.hdr, &a.ofrag_recs, &a.pixel_state, &a.tile_first};
+        for (DevBuf* b : alts) b->release();
+    }
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release();
-    for (int i = 0; i < 20; i++) if (c->ev_sets[i / 10][i % 10]) (void)hipEventDestroy(c->ev_sets[i / 10][i % 10]);
+    for (int i = 0; i < 10 * RDR_FRAME_SLOTS; i++) if (c->ev_sets[i / 10][i % 10]) (void)hipEventDestroy(c->ev_sets[i / 10][i % 10]);
     if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_raster1) (void)hipEventDestroy(c->ev_raster1);
-    for (int i = 0; i < 2; i++) if (c->ev_shaded[i]) (void)hipEventDestroy(c->ev_shaded[i]);
+    for (int i = 0; i < RDR_FRAME_SLOTS; i++) if (c->ev_shaded[i]) (void)hipEventDestroy(c->ev_shaded[i]);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -1643,18 +1651,19 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     RDR_TRY(upload_scene(c));
     RDR_TRY(run_skinning(c));
     RDR_TRY(ensure_post_targets(c));
-    c->slot = (int)(c->frames & 1u);
+    c->slot = (int)(c->frames % RDR_FRAME_SLOTS);
     c->ev = c->ev_sets[c->slot];
-    if (c->pending[c->slot].on) {  // the frame before the previous one was never picked up: it has long finished
+    if (c->pending[c->slot].on) {  // the last frame of this slot was never picked up: it has long finished
         HIP_TRY(hipEventSynchronize(c->ev[5]));
         harvest(c, c->slot);
     }
-    {   // this frame's geometry phase writes the set the frame before the previous one used
-        rdr_ctx::AltBuffers& o = c->alt;
+    // this frame writes the buffer set the last frame of its slot used: the sets rotate, the oldest comes to the front
+    for (int a = 0; a < RDR_FRAME_SLOTS - 1; a++) {
+        rdr_ctx::AltBuffers& o = c->alt[a];
         std::swap(c->d_batch_tables, o.batch_tables); std::swap(c->d_frame, o.frame); std::swap(c->d_shade_tris, o.shade_tris);
         std::swap(c->d_recs, o.recs); std::swap(c->d_tile_start, o.tile_start); std::swap(c->d_depth, o.depth); std::swap(c->d_vis, o.vis);
         std::swap(c->d_dir_shadow, o.dir_shadow); std::swap(c->d_hdr, o.hdr);
-        // the 4x rasteriser of this frame fills the fragment lists while the previous frame is still shaded from its own
+        // the 4x rasteriser of this frame fills the fragment lists while the frames before are still shaded from their own
         std::swap(c->d_ofrag_recs, o.ofrag_recs); std::swap(c->d_pixel_state, o.pixel_state); std::swap(c->d_tile_first, o.tile_first);
         for (int k = 0; k < 2; k++) { std::swap(c->d_keys[k], o.keys[k]); std::swap(c->d_vals[k], o.vals[k]); }
     }
@@ -1760,7 +1769,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         // its own pinned block, one half per frame slot: the copy out of a half was enqueued two frames ago, in front
         // of work the previous frame's pair-count wait has since seen finished
         const size_t half = (off_l + sz_l + 63) & ~(size_t)63;
-        HIP_TRY(c->h_frame.ensure(2 * half));
+        HIP_TRY(c->h_frame.ensure(RDR_FRAME_SLOTS * half));
         uint8_t* st = c->h_frame.as<uint8_t>() + (size_t)c->slot * half;
         memcpy(st, &fr, sizeof fr);
         memcpy(st + off_l, dl.data(), sz_l);
@@ -1892,11 +1901,13 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     c->stats.draw_lists_on_device = c->device_draws ? 1u : 0u;
     c->pending[c->slot].on = true;
     c->pending[c->slot].host = c->stats;
-    // The frame before this one has had the whole set-up of this one to finish its tail: its results are picked up
-    // now, so that it is complete (image, luminance, counters) when this call returns.
-    if (c->pending[c->slot ^ 1].on) {
-        HIP_TRY(hipEventSynchronize(c->ev_sets[c->slot ^ 1][5]));
-        harvest(c, c->slot ^ 1);
+    // The frame `lag` calls back has had the whole set-up of the frames since to finish its tail: its results are
+    // picked up now, so that it is complete (image, luminance, counters) when this call returns.
+    for (int age = RDR_FRAME_SLOTS - 1; age >= c->lag; age--) {
+        const int s = (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS;
+        if (!c->pending[s].on) continue;
+        HIP_TRY(hipEventSynchronize(c->ev_sets[s][5]));
+        harvest(c, s);
     }
     // With a device destination the call only enqueues; rdr_synchronize(), or the next frame, picks up the luminance
     // and the counters.
@@ -1918,8 +1929,9 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream4);
         (void)hipGetLastError();
         c->pending[c->slot].on = false;
-        c->cascades_key[0].valid = c->cascades_key[1].valid = c->point_dynamic_key.valid = false;  // targets may be half written
-        harvest(c, c->slot ^ 1);
+        for (rdr_ctx::ShadowKey& k : c->cascades_key) k.valid = false;  // targets may be half written
+        c->point_dynamic_key.valid = false;
+        for (int age = RDR_FRAME_SLOTS - 1; age >= 1; age--) harvest(c, (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS);
         c->err = keep;
     }
     return rc;
@@ -1932,8 +1944,21 @@ int rdr_synchronize(rdr_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream3));
     HIP_TRY(hipStreamSynchronize(c->stream2));
     HIP_TRY(hipStreamSynchronize(c->stream4));
-    harvest(c, c->slot ^ 1);  // the older frame first, so that done_stats ends up holding the newest
-    harvest(c, c->slot);
+    // the oldest frame first, so that done_stats ends up holding the newest
+    for (int age = RDR_FRAME_SLOTS - 1; age >= 0; age--) harvest(c, (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS);
+    return RDR_OK;
+}
+
+int rdr_wait_frame(rdr_ctx* c, uint64_t frame_index) {
+    if (!c) return RDR_ERR_INVALID;
+    if (frame_index > c->frames) return fail(c, RDR_ERR_INVALID, "wait_frame: that frame has not been enqueued");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int age = RDR_FRAME_SLOTS - 1; age >= 0; age--) {  // oldest first
+        const int s = (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS;
+        if (!c->pending[s].on || c->pending[s].host.frame_index > frame_index) continue;
+        HIP_TRY(hipEventSynchronize(c->ev_sets[s][5]));
+        harvest(c, s);
+    }
     return RDR_OK;
 }
 

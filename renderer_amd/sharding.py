@@ -7,12 +7,12 @@ process per GPU, `torch.distributed` with the "nccl" backend (RCCL over xGMI);
 the same code runs with "gloo" and host tensors, which is how it is tested
 without GPUs.
 
-Two frames are in flight on a GPU: frame k is only enqueued, the host goes on to
-build and enqueue frame k+1 behind it, and frame k's image and luminance are
-collected when that call returns (the renderer guarantees frame k is complete
-by then). The gather of frame k is issued asynchronously at that point and
-waited for only when its staging slot is needed again, so it overlaps the
-rendering of the next frames.
+Up to three frames are in flight on a GPU: frame k is only enqueued, the host
+goes on to build and enqueue the frames behind it, and frame k's image and
+luminance are collected when the renderer reports it complete (two calls later
+at the latest, or after wait_frame). The gather of frame k is issued
+asynchronously at that point and waited for only when its staging slot is
+needed again, so it overlaps the rendering of the next frames.
 Rank 0 receives over up to R-1 distinct xGMI links at once (a 4K RGBA8 frame is
 33 MB, about 0.2 ms per link), which is why a plain gather is used rather than
 a ring all-gather.
@@ -41,9 +41,10 @@ class FrameSharder:
     renderer  : api.Renderer bound to this rank's GPU
     dist      : the initialised torch.distributed module, or None for a single process
     device    : torch device of the staging tensors ("cuda:N" with nccl, "cpu" with gloo)
-    depth     : staging slots; depth-1 gathers can be in flight while a frame renders
-    pipelined : keep two frames in flight on the renderer (a frame is only enqueued; its results are collected once the
-                next one has been enqueued behind it). Default: on for device staging tensors, off for host ones.
+    depth     : staging slots: a slot is busy from the call that renders into it until the gather of its frame has
+                finished; with fewer than three the renderer is made to wait for a frame before its slot is reused
+    pipelined : keep frames in flight on the renderer (a frame is only enqueued; its results are collected once the
+                renderer reports it complete). Default: on for device staging tensors, off for host ones.
     After `run`, `gather_wait_s` is the time this rank spent waiting for gathers it had issued (rank 0: for the frames
     of all ranks to arrive) and `frames_rendered` the frames it rendered itself.
     """
@@ -72,7 +73,7 @@ class FrameSharder:
     # -- one frame ---------------------------------------------------------
     def _render_into(self, tensor, frame_params):
         """Renders into `tensor`. A device tensor only gets the frame enqueued (returns None: the frame's results are
-        picked up by `_collect` once the next frame has been enqueued behind it, or after `synchronize`); a host
+        picked up by `_collect` once the renderer reports it complete); a host
         tensor is rendered to completion and its average log-luminance returned."""
         self.frames_rendered += 1
         if self.pipelined:
@@ -119,7 +120,7 @@ class FrameSharder:
         frame_params = dict(frame_params or {})
         n_rounds = rounds(n_frames, self.world)
         first_index = self.r.frame_stats().frame_index + 1 if self.pipelined else 0  # index of this job's frame 0
-        in_flight = None  # (round, frame) enqueued on the GPU whose results have not been collected yet
+        in_flight = []  # (round, frame or None) enqueued on the GPU, oldest first, whose results have not been collected
 
         def finish(entry):
             # the frame is complete: collect its results, then hand its image to the gather
@@ -133,8 +134,18 @@ class FrameSharder:
                 work = self.dist.gather(self.slots[slot_f], self.recv[slot_f] if self.rank == 0 else None, dst=0, async_op=True)
             self.pending[slot_f] = (work, rnd_f, n_valid)
 
+        def finish_through(last_round):
+            # waits, oldest first, for the frames of the rounds up to `last_round` and finishes them
+            while in_flight and in_flight[0][0] <= last_round:
+                entry = in_flight.pop(0)
+                if entry[1] is not None:
+                    self.r.wait_frame(first_index + entry[1] // self.world)
+                finish(entry)
+
         for rnd in range(n_rounds):
             slot = rnd % self.depth
+            if self.pipelined:
+                finish_through(rnd - self.depth)  # the frame that was rendered into this slot, if it is still in flight
             self._retire(slot, on_frame)
             k = rnd * self.world + self.rank
             avg = None
@@ -142,27 +153,27 @@ class FrameSharder:
                 set_frame(self.r, k)
                 avg = self._render_into(self.slots[slot], frame_params)
             if self.pipelined:
-                # two frames in flight: frame k was only enqueued, and by now the frame before it has finished
-                # (a rank without a frame in this round enqueued nothing behind it and has to wait for it)
-                if in_flight is not None:
-                    if k >= n_frames:
-                        self.r.synchronize()
-                    finish(in_flight)
-                in_flight = (rnd, k if k < n_frames else None)
+                # frames in flight: frame k was only enqueued; the call has picked up the results of the frames that
+                # have finished by now (the renderer says which: at most one more per call), and those are finished
+                # here. A rank without a frame in this round enqueued nothing and waits for what it has in flight.
+                in_flight.append((rnd, k if k < n_frames else None))
+                if k >= n_frames:
+                    finish_through(rnd)
+                else:
+                    done = self.r.frame_stats().frame_index
+                    while in_flight and in_flight[0][1] is not None and first_index + in_flight[0][1] // self.world <= done:
+                        finish(in_flight.pop(0))
             else:
                 if k < n_frames:
                     self.luminance[k] = avg
                     if after_render is not None:
                         after_render(k)
-                in_flight = None
                 n_valid = min(self.world, n_frames - rnd * self.world)
                 work = None
                 if self.dist:
                     work = self.dist.gather(self.slots[slot], self.recv[slot] if self.rank == 0 else None, dst=0, async_op=True)
                 self.pending[slot] = (work, rnd, n_valid)
-        if in_flight is not None:
-            self.r.synchronize()
-            finish(in_flight)
+        finish_through(n_rounds)
         # drain in round order
         order = sorted((p[1], s) for s, p in enumerate(self.pending) if p is not None)
         for _, s in order:
