@@ -133,10 +133,12 @@ def test_exposure_sequence_follows_the_reference_recurrence():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("in_flight", [2, 3])
 @pytest.mark.parametrize("exposure_mode", [1, 0])
-def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi, exposure_mode):
-    """Frames enqueued back to back into device tensors (the sharder keeps two in flight and collects frame k after
-    frame k+1 has been enqueued) against the same frames rendered to completion one at a time: same images, same
+def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi, exposure_mode, in_flight, monkeypatch):
+    """Frames enqueued back to back into device tensors (two or, with RDR_FRAMES_IN_FLIGHT=3, three in flight; the
+    sharder collects a frame once the renderer reports it complete, and has two staging tensors, so with three in flight
+    it waits for a frame before reusing its tensor) against the same frames rendered to completion one at a time: same images, same
     per-frame luminance and counters, and the statistics carry the right frame index. With exposure_mode 0 every
     frame's exposure follows from the luminance of the frame before it (the reference's recurrence), which the
     renderer has to wait for in the middle of the next frame."""
@@ -146,6 +148,7 @@ def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi, exposure_
     from renderer_amd.api import Renderer, default_settings
 
     W, H, n = 200, 120, 5
+    monkeypatch.setenv("RDR_FRAMES_IN_FLIGHT", str(in_flight))
 
     def build():
         r = Renderer(hip_capi, W, H, default_settings(msaa=4, directional_shadow_map_resolution=512, point_shadow_map_resolution=128))
@@ -187,8 +190,9 @@ def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi, exposure_
 
 
 @pytest.mark.gpu
-def test_frames_in_flight_with_changing_scene_state(hip_capi):
-    """Between frames that are still in flight the caller moves the camera, a dynamic mesh and the lights, and now and
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_frames_in_flight_with_changing_scene_state(hip_capi, in_flight, monkeypatch):
+    """Between frames that are still in flight (two, or three with RDR_FRAMES_IN_FLIGHT=3) the caller moves the camera, a dynamic mesh and the lights, and now and
     then asks for a frame in host memory (which drains the pipeline). Every frame must equal the same frame rendered by
     a second context one frame at a time: nothing a frame reads may be overwritten by the frame enqueued behind it."""
     import torch
@@ -197,6 +201,7 @@ def test_frames_in_flight_with_changing_scene_state(hip_capi):
     from renderer_amd.api import Renderer, default_settings
 
     W, H, n = 160, 96, 9
+    monkeypatch.setenv("RDR_FRAMES_IN_FLIGHT", str(in_flight))
 
     def build():
         r = Renderer(hip_capi, W, H, default_settings(msaa=4, directional_shadow_map_resolution=256, point_shadow_map_resolution=64))
