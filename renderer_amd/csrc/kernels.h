@@ -50,7 +50,12 @@ struct RasterRange { uint32_t first_tile, end_tile, first_view; };
 // the views of one rasteriser launch, passed by value in the kernel arguments
 #define RDR_RASTER_MAX_VIEWS 32
 struct RasterViews {
-    uint32_t n, first_tile, end_tile, _pad;
+    uint32_t n, first_tile, end_tile;
+    // Which tiles of the launch store their depth: 0 all; 1 only those with a blended triangle (the blended pass reads
+    // and writes their depth: what the frame itself needs); 2 only those without (what rdr_read_depth asks for later:
+    // a second pass over the same lists, for the tiles the first left out). `blend_base`: first entry of the blended
+    // view's tile lists in tile_start / tile_end, 0xFFFFFFFF when there is no such view.
+    uint32_t depth_mode, blend_base, _pad[3];
     uint32_t base[RDR_RASTER_MAX_VIEWS];  // first tile of view k (0xFFFFFFFF past the last)
     DView v[RDR_RASTER_MAX_VIEWS];
 };
@@ -58,7 +63,8 @@ struct RasterViews {
 // they are still in LDS (then launch_frag_classify is not needed); null otherwise
 struct FragLists;
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DView* d_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples, const FragLists* classify = nullptr);
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples, const FragLists* classify = nullptr,
+                   uint32_t depth_mode = 0u, uint32_t blend_base = 0xFFFFFFFFu);
 
 // kernels_shade.hip
 void launch_shade_setup(hipStream_t s, const DFrame* fr, const DDraw* draws, const uint32_t* first_tri, uint32_t n_draws, uint32_t n_tris,

@@ -560,6 +560,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
     if (local_tile >= vw.tiles_x * vw.tiles_y) continue;
     const int ox0 = (int)(local_tile % vw.tiles_x) * RDR_TILE, oy0 = (int)(local_tile / vw.tiles_x) * RDR_TILE;
     const size_t plane_px = (size_t)vw.pitch * vw.h;
+    bool store_depth = true;
+    if (tbl.depth_mode) {
+        const bool has_blend = tbl.blend_base != 0xFFFFFFFFu && tile_start[tbl.blend_base + local_tile] < tile_end[tbl.blend_base + local_tile];
+        store_depth = (tbl.depth_mode == 1u) == has_blend;
+        if (tbl.depth_mode == 2u && !store_depth) continue;  // stored by the first pass (and changed by the blended pass since)
+    }
     if (begin >= end) {                   // nothing drawn here: the tile is just cleared ...
         if (S == 1 && vw.load) continue;  // ... or, for a view that adds to what its target holds, left as it is
 #pragma unroll
@@ -569,7 +575,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
                 const size_t at = (size_t)cy * vw.pitch + cx;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    vw.depth[s * plane_px + at] = 1.0f;
+                    if (store_depth) vw.depth[s * plane_px + at] = 1.0f;
                     if (vw.vis) vw.vis[s * plane_px + at] = RDR_PAIR_INVALID;
                 }
             }
@@ -753,8 +759,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
 #pragma unroll
         for (int s = 0; s < S; s++) key[s] = lds_key[s * 256 + pix];
         // every pixel is stored, changed or not: whole sectors go out, none has to be merged in memory
+        if (store_depth) {
 #pragma unroll
-        for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
+            for (int s = 0; s < S; s++) vw.depth[s * plane_px + o] = __uint_as_float((uint32_t)(key[s] >> 32));
+        }
         uint32_t vid[S];
 #pragma unroll
         for (int s = 0; s < S; s++) vid[s] = key[s] != ((unsigned long long)(S == 1 ? zi1[q] : ONE) << 32) ? (uint32_t)key[s] : RDR_PAIR_INVALID;
@@ -860,7 +868,8 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32
 // `samples`, RDR_RASTER_MAX_VIEWS of them per launch. `views` is the host copy of the batch's view table, `d_views` the
 // device copy (single-sampled targets are first brought to their initial state from it, k_view_init).
 void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DView* d_views, const DTriRec* recs, const uint32_t* sorted_vals,
-                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples, const FragLists* classify) {
+                   const uint32_t* tile_start, const uint32_t* tile_end, RasterRange r, int samples, const FragLists* classify, uint32_t depth_mode,
+                   uint32_t blend_base) {
     if (r.first_tile >= r.end_tile) return;
     uint32_t last = r.first_view;
     while (last + 1 < n_views && views[last + 1].tile_base < r.end_tile) last++;
@@ -876,6 +885,8 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DV
         for (uint32_t k = 0; k < tbl.n; k++) { tbl.v[k] = views[v0 + k]; tbl.base[k] = views[v0 + k].tile_base; }
         for (uint32_t k = tbl.n; k < RDR_RASTER_MAX_VIEWS; k++) tbl.base[k] = 0xFFFFFFFFu;
         tbl.first_tile = tbl.base[0];
+        tbl.depth_mode = samples == 4 ? depth_mode : 0u; tbl.blend_base = blend_base;
+        tbl._pad[0] = tbl._pad[1] = tbl._pad[2] = 0u;
         const DView& lv = tbl.v[tbl.n - 1];
         tbl.end_tile = lv.tile_base + lv.tiles_x * lv.tiles_y;
         const uint32_t n_tiles = tbl.end_tile - tbl.first_tile;

@@ -207,6 +207,14 @@ struct rdr_ctx {
     DevBuf d_frags, d_frag_col, d_frag_head, d_tile_slots;
     // opaque pass: fragment records and colours (one list per screen rectangle), per-pixel state, first fragment per tile
     DevBuf d_ofrag_recs, d_ofrag_cols, d_pixel_state, d_tile_first;
+    // The last frame's 4x rasteriser stored depth only in the tiles the blended pass works on (nothing else in a frame
+    // reads the main view's depth): rdr_read_depth first runs the rasteriser over the other tiles again, from the
+    // frame's triangle records and sorted tile lists, which stay as they are until the slot's next frame.
+    bool depth_partial = false;
+    DView depth_view{};
+    RasterRange depth_range{};
+    int depth_cur = 0;
+    uint32_t depth_blend_base = 0xFFFFFFFFu;
     bool vis_in_lists = false;  // the last frame's visibility lives in its fragment lists (rdr_read_visibility unpacks it)
     uint32_t shade_blocks = 1024;  // grid of the fragment shading kernel: four 256-thread blocks per compute unit
     uint64_t blend_budget_slots = 48ull << 20;  // fragment-list slots (32 B each) a frame may use at once; RDR_BLEND_BUDGET_SLOTS overrides (tests)  // the count of used fragment slots is word RDR_COUNTER_FRAGS of d_counters
@@ -818,11 +826,27 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
     if (rs != c->stream) HIP_TRY(hipStreamWaitEvent(rs, c->ev_fork, 0));
     HIP_TRY(hipEventRecord(c->ev[8], rs));
     const RasterRange none = {0xFFFFFFFFu, 0u, 0u};
+    // a frame whose fragment lists come from the rasteriser stores the main view's depth only where the blended pass
+    // needs it (RDR_FULL_DEPTH=1: everywhere, a measurement aid)
+    uint32_t depth_mode = 0u, blend_base = 0xFFFFFFFFu;
+    if (main_batch && classify && rr[2].first_tile < rr[2].end_tile && !getenv("RDR_FULL_DEPTH")) {
+        depth_mode = 1u;
+        const DView& mv = b.views[rr[2].first_view];
+        for (const DView& v : b.views)
+            if (v.load == 2u && v.samples == 4u && v.depth == mv.depth) blend_base = v.tile_base;
+        c->depth_partial = true;
+        c->depth_view = mv; c->depth_view.vis = nullptr;
+        c->depth_range = rr[2]; c->depth_range.first_view = 0u;
+        c->depth_cur = cur;
+        c->depth_blend_base = blend_base;
+    } else if (main_batch) {
+        c->depth_partial = false;
+    }
     auto launch = [&](hipStream_t st, const RasterRange& s1, const RasterRange& s4) {
         launch_raster(st, b.views.data(), (uint32_t)b.views.size(), c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
                       c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s1, 1);
         launch_raster(st, b.views.data(), (uint32_t)b.views.size(), c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
-                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s4, 4, classify);
+                      c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), s4, 4, classify, depth_mode, blend_base);
     };
     // RDR_SERIAL_RASTER: measurement aid, the rasterisers one after the other so that a profile shows each alone
     const bool side = rr[2].first_tile < rr[2].end_tile && (rr[0].first_tile < rr[0].end_tile || rr[1].first_tile < rr[1].end_tile) && !getenv("RDR_SERIAL_RASTER");
@@ -1991,6 +2015,14 @@ static int read_back_2d(rdr_ctx* c, float* dst, const float* src, size_t pitch, 
 
 int rdr_read_depth(rdr_ctx* c, float* out) {
     if (!c || !out || !c->have_frame) return fail(c, RDR_ERR_INVALID, "read_depth: no frame");
+    if (c->depth_partial) {
+        HIP_TRY(hipSetDevice(c->device));
+        RDR_TRY(rdr_synchronize(c));
+        launch_raster(c->stream2, &c->depth_view, 1u, nullptr, c->d_recs.as<DTriRec>(), c->d_vals[c->depth_cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
+                      c->d_tile_end.as<uint32_t>(), c->depth_range, 4, nullptr, 2u, c->depth_blend_base);
+        HIP_TRY(hipGetLastError());
+        c->depth_partial = false;  // the image is whole now
+    }
     return read_back(c, out, c->d_depth.p, (size_t)c->W * c->H * c->settings.msaa * 4);
 }
 int rdr_read_visibility(rdr_ctx* c, uint32_t* out) {
