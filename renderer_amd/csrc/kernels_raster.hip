@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 #ifndef RDR_RASTER_K1
 #define RDR_RASTER_K1 1
 #endif
+#ifndef RDR_RASTER_DIAG
+#define RDR_RASTER_DIAG 0  // diagnostic builds only: bit 0 no per-pixel items, bit 1 every tile taken as empty
+#endif
 #ifndef RDR_RASTER_K4
 #define RDR_RASTER_K4 1
 #endif
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
         store_depth = (tbl.depth_mode == 1u) == has_blend;
         if (tbl.depth_mode == 2u && !store_depth) continue;  // stored by the first pass (and changed by the blended pass since)
     }
-    if (begin >= end) {                   // nothing drawn here: the tile is just cleared ...
+    if (begin >= end || (RDR_RASTER_DIAG & 2)) {  // nothing drawn here: the tile is just cleared ...
         if (S == 1 && vw.load) continue;  // ... or, for a view that adds to what its target holds, left as it is
 #pragma unroll
         for (int q = 0; q < Q; q++) {
@@ -676,7 +679,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
             if (tid == 0) lds_prefix[0] = 0u;
         }
         __syncthreads();
-        const uint32_t total = lds_prefix[RASTER_CHUNK];
+        const uint32_t total = (RDR_RASTER_DIAG & 1) ? 0u : lds_prefix[RASTER_CHUNK];
         for (uint32_t wi = (uint32_t)tid; wi < total; wi += (uint32_t)T) {
             // largest lo with prefix[lo] <= wi; entries past the last record hold the total, which is > wi
             uint32_t lo = 0;
