@@ -331,7 +331,9 @@ int rdr_get_frame_stats(rdr_ctx* ctx, rdr_frame_stats* out);
 /* ---- debug read-backs (needed for bit-exact parity tests) -------------- */
 
 /* main-pass depth after the whole pass, sample-major: out[s*W*H + y*W + x],
- * `samples` = settings.msaa. */
+ * `samples` = settings.msaa. A 4x frame stores depth only where its blended
+ * pass reads it; the first call after such a frame waits for the frame and
+ * rasterises the remaining tiles again (valid until the next render call). */
 int rdr_read_depth(rdr_ctx* ctx, float* out);
 /* main-pass visibility after the OPAQUE draws: id of the covering triangle
  * (draw-order index of the primitive in the high 8+ bits is NOT encoded; the
