@@ -773,24 +773,24 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_r
 #pragma unroll
             for (int s = 0; s < S; s++) vw.vis[s * plane_px + o] = vid[s];
         }
-        if (CLASSIFY) {
-            // the u-th distinct triangle of the pixel (15: the sample saw none)
-            uint32_t n_unique = 0u, st = 0u;
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                uint32_t u = 15u;
-                if (vid[s] != RDR_PAIR_INVALID) {
-                    u = n_unique;
-#pragma unroll
-                    for (int k = S - 1; k >= 0; k--) if ((uint32_t)k < n_unique && cls_ids[q][k] == vid[s]) u = (uint32_t)k;
-                    if (u == n_unique) {  // (written without a variable index: the ids stay in registers)
-#pragma unroll
-                        for (int k = 0; k < S; k++) if ((uint32_t)k == n_unique) cls_ids[q][k] = vid[s];
-                        n_unique++;
-                    }
-                }
-                st |= u << (16 + 4 * s);
-            }
+        if constexpr (CLASSIFY) {
+            // the u-th distinct triangle of the pixel, in order of first appearance (15: the sample saw none), from the
+            // six comparisons between its four samples; two equal ids are both valid, so only the sample itself is checked
+            const bool v0 = vid[0] != RDR_PAIR_INVALID, v1 = vid[1] != RDR_PAIR_INVALID, v2 = vid[2] != RDR_PAIR_INVALID, v3 = vid[3] != RDR_PAIR_INVALID;
+            const bool e10 = vid[1] == vid[0], e20 = vid[2] == vid[0], e21 = vid[2] == vid[1];
+            const bool e30 = vid[3] == vid[0], e31 = vid[3] == vid[1], e32 = vid[3] == vid[2];
+            const bool n1 = v1 && !e10, n2 = v2 && !e20 && !e21, n3 = v3 && !e30 && !e31 && !e32;  // first appearances (sample 0: v0)
+            const uint32_t r1 = v0 ? 1u : 0u, r2 = r1 + (n1 ? 1u : 0u), r3 = r2 + (n2 ? 1u : 0u);  // distinct triangles before the sample
+            const uint32_t n_unique = r3 + (n3 ? 1u : 0u);
+            const uint32_t u0 = v0 ? 0u : 15u;
+            const uint32_t u1 = !v1 ? 15u : (e10 ? u0 : r1);
+            const uint32_t u2 = !v2 ? 15u : (e20 ? u0 : (e21 ? u1 : r2));
+            const uint32_t u3 = !v3 ? 15u : (e30 ? u0 : (e31 ? u1 : (e32 ? u2 : r3)));
+            const uint32_t st = (u0 << 16) | (u1 << 20) | (u2 << 24) | (u3 << 28);
+            cls_ids[q][0] = v0 ? vid[0] : (n1 ? vid[1] : (n2 ? vid[2] : vid[3]));
+            cls_ids[q][1] = (n1 && r1 == 1u) ? vid[1] : ((n2 && r2 == 1u) ? vid[2] : vid[3]);
+            cls_ids[q][2] = (n2 && r2 == 2u) ? vid[2] : vid[3];
+            cls_ids[q][3] = vid[3];
             cls_n[q] = n_unique; cls_state[q] = st;
         }
     }
