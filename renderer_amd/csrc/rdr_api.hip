@@ -241,6 +241,7 @@ struct rdr_ctx {
     struct PendingFrame { bool on = false; rdr_frame_stats host{}; } pending[RDR_FRAME_SLOTS];
     uint64_t frames = 0;           // frames enqueued so far
     int slot = 0;                  // frame slot of the frame being enqueued (frames enqueued before it, modulo RDR_FRAME_SLOTS)
+    bool tail_split = true;        // resolve and blended pass on the tail stream (RDR_TAIL_ON_SHADING_STREAM=1: on the shading stream)
     int lag = 1;                   // a call returns once the frame `lag` calls back has finished and been picked up (RDR_FRAMES_IN_FLIGHT - 1)
     hipEvent_t ev_sets[RDR_FRAME_SLOTS][10] = {};
     hipEvent_t* ev = ev_sets[0];   // the events of the frame being enqueued
@@ -253,13 +254,13 @@ struct rdr_ctx {
     bool raster_side = false;         // ... and its 4x rasteriser ran on stream3 (ev_join)
     hipStream_t raster_stream = nullptr;  // stream the shadow-view rasteriser of the last batch was enqueued on
     // Geometry and shading of consecutive frames overlap: `stream` carries the geometry phase of a frame (set-up, binning,
-    // sort, rasterisers; `stream3` takes the 4x rasteriser beside the shadow-view one), `stream2` its shading, blended
-    // pass and tail. What the geometry phase writes and the shading reads exists twice (`alt` holds the set of the
+    // sort; `stream3` takes the 4x rasteriser), `stream2` the shadow-view rasteriser and the shading kernel, `stream4`
+    // what follows it (resolve, blended pass, post chain). What the geometry phase writes and the shading reads exists twice (`alt` holds the set of the
     // other frame slot; the two are swapped at the start of every frame), so the geometry phase of frame k+1 runs
     // while frame k is shaded. The point-light shadow maps exist once (a face nothing moves in keeps what it held):
     // their rasteriser launch waits for the previous frame's shading (ev_shaded).
     hipStream_t stream3 = nullptr;
-    hipStream_t stream4 = nullptr;  // the tail of a frame (bloom chain, tonemap, luminance, read-backs), beside the next frame's shading
+    hipStream_t stream4 = nullptr;  // the tail of a frame (resolve, blended pass, bloom chain, tonemap, luminance, read-backs), beside the next frame's rasterisers and shading
     hipEvent_t ev_shaded[RDR_FRAME_SLOTS] = {};
     struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr, ofrag_recs, pixel_state, tile_first; } alt[RDR_FRAME_SLOTS - 1];
     PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
@@ -1182,6 +1183,7 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     if (const char* e = getenv("RDR_BLEND_BUDGET_SLOTS")) { const long long v = atoll(e); if (v > 0) c->blend_budget_slots = (uint64_t)v; }
     // 2 or 3 frames in flight (2 by default: a frame's results are there one call later; 3 gave +1 % frames/s on the
     // benchmark frame and a shading kernel 2 % longer for what runs beside it)
+    if (getenv("RDR_TAIL_ON_SHADING_STREAM")) c->tail_split = false;
     if (const char* e = getenv("RDR_FRAMES_IN_FLIGHT")) { const int v = atoi(e); if (v == 2 || v == 3) c->lag = v - 1; }
     // measurement aid: size of the fragment shading kernel's grid (a multiple of 8, one share per die)
     if (const char* e = getenv("RDR_SHADE_BLOCKS")) { const long v = atol(e); if (v >= 8 && v <= 65536) c->shade_blocks = (uint32_t)v & ~7u; }
@@ -1835,13 +1837,21 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     // behind the previous frame's shading and tail
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_raster1, 0));
     if (c->raster_side) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_join, 0));
+    // What follows the shading kernel (resolve, blended pass) goes to the tail stream in front of the post chain: the
+    // shading stream then holds only shadow-view rasterisers and shading kernels, and the next frame's rasteriser does
+    // not queue behind this frame's blended pass. The fragment colours exist once, so the shading kernel waits for
+    // the resolve of the frame before (ev[9] of its slot).
+    hipStream_t ts = c->tail_split ? c->stream4 : c->stream2;
     {
         if (!fused_classify) launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_vis.as<uint32_t>(), L);
+        if (ts != c->stream2 && c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_sets[prev_slot(c)][9], 0));
         HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
         launch_shade_frags(c->stream2, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, L, c->shade_blocks);
         HIP_TRY(hipEventRecord(c->ev[7], c->stream2));
-        launch_frag_resolve(c->stream2, (int)S, c->d_frame.as<DFrame>(), L, c->d_hdr.p, (S == 4 && have_blend) ? c->d_samples.p : nullptr,
+        if (ts != c->stream2) HIP_TRY(hipStreamWaitEvent(ts, c->ev[7], 0));
+        launch_frag_resolve(ts, (int)S, c->d_frame.as<DFrame>(), L, c->d_hdr.p, (S == 4 && have_blend) ? c->d_samples.p : nullptr,
                             c->d_tile_start.as<uint32_t>() + blend_tile_base, c->d_tile_end.as<uint32_t>() + blend_tile_base, W, H);
+        HIP_TRY(hipEventRecord(c->ev[9], ts));
     }
     HIP_TRY(hipGetLastError());
 
@@ -1855,7 +1865,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         const uint64_t bound = blocks * 4u * RDR_FRAG_RUN + 2u * c->blend_box_pixels + RDR_FRAG_RUN;
         HIP_TRY(c->d_frag_head.ensure(n * 4));
         auto run_group = [&](uint32_t tile0, uint32_t count, uint32_t capacity) {
-            launch_raster_blend(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), c->d_views.as<DView>() + (main_view + 1),
+            launch_raster_blend(ts, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), c->d_views.as<DView>() + (main_view + 1),
                                 tris_blend, c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
                                 c->d_tile_end.as<uint32_t>(), tile0, count, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p,
                                 c->d_frag_col.p, c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, capacity);
@@ -1870,12 +1880,12 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
             // rendered in groups that fit the list, one collect / shade / resolve sequence per group. Blending is per
             // pixel, so the order of the groups does not matter.
             HIP_TRY(c->d_tile_slots.ensure((size_t)n_tiles * 4));
-            HIP_TRY(hipMemsetAsync(c->d_tile_slots.p, 0, (size_t)n_tiles * 4, c->stream2));
-            launch_blend_count(c->stream2, (int)S, c->d_views.as<DView>() + (main_view + 1), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
+            HIP_TRY(hipMemsetAsync(c->d_tile_slots.p, 0, (size_t)n_tiles * 4, ts));
+            launch_blend_count(ts, (int)S, c->d_views.as<DView>() + (main_view + 1), c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(),
                                c->d_tile_start.as<uint32_t>(), c->d_tile_end.as<uint32_t>(), n_tiles, c->d_tile_slots.as<uint32_t>());
             std::vector<uint32_t> slots(n_tiles);
-            HIP_TRY(hipMemcpyAsync(slots.data(), c->d_tile_slots.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, c->stream2));
-            HIP_TRY(hipStreamSynchronize(c->stream2));
+            HIP_TRY(hipMemcpyAsync(slots.data(), c->d_tile_slots.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, ts));
+            HIP_TRY(hipStreamSynchronize(ts));
             uint64_t largest = 0;
             for (uint32_t t = 0; t < n_tiles; t++) largest = std::max<uint64_t>(largest, slots[t]);
             const uint64_t list = std::max<uint64_t>(c->blend_budget_slots, largest) + RDR_FRAG_RUN;
@@ -1887,7 +1897,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
                 uint32_t t1 = t0;
                 while (t1 < n_tiles && (t1 == t0 || sum + slots[t1] <= c->blend_budget_slots)) sum += slots[t1++];
                 if (sum) {
-                    if (t0) HIP_TRY(hipMemsetAsync(frame_counters(c) + RDR_COUNTER_FRAGS, 0, 4, c->stream2));
+                    if (t0) HIP_TRY(hipMemsetAsync(frame_counters(c) + RDR_COUNTER_FRAGS, 0, 4, ts));
                     run_group(t0, t1 - t0, (uint32_t)list);
                     c->stats.blend_groups++;
                 }
@@ -1906,7 +1916,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     const float exposure = compute_exposure(c, fp);
     // a device destination receives the frame straight from the tonemap kernel (its 8-byte stores need the alignment)
     uint32_t* direct_out = (out_rgba8 && out_is_device && ((uintptr_t)out_rgba8 & 7u) == 0) ? (uint32_t*)out_rgba8 : nullptr;
-    HIP_TRY(hipEventRecord(c->ev_shaded[c->slot], c->stream2));  // the shadow maps and the geometry phase's outputs have been read
+    HIP_TRY(hipEventRecord(c->ev_shaded[c->slot], ts));  // the shadow maps and the geometry phase's outputs have been read
     HIP_TRY(hipStreamWaitEvent(c->stream4, c->ev_shaded[c->slot], 0));  // the tail has its own stream: the next frame's shading does not queue behind it
     enqueue_post(c, c->stream4, exposure, direct_out);
     HIP_TRY(hipGetLastError());
