@@ -394,7 +394,7 @@ RDR_DEV uint32_t wave_upper_index(const uint32_t* __restrict__ offset, uint32_t 
 // instances without pairs - are searched in global memory, between the two ends.) The chain of dependent loads per
 // pair is 5 long instead of 20, which matters most when this kernel runs beside the previous frame's shading.
 #define EMIT_SPAN 2048u
-__global__ void __launch_bounds__(256) k_emit(const DView* __restrict__ views, const DTriRec* __restrict__ recs,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_emit(const DView* __restrict__ views, const DTriRec* __restrict__ recs,
                                               const uint32_t* __restrict__ pair_offset, uint32_t n_inst, uint32_t n_pairs,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     __shared__ uint32_t lds_off[EMIT_SPAN];
