@@ -387,6 +387,10 @@ int rdr_post_process(rdr_ctx* ctx, const float* hdr_rgba_f32, float exposure, ui
  * or other allocating routine: the bloom chain, the log-luminance image and the partial means of the luminance
  * reduction live in a fixed array inside the library's code object (about 21 MB per GPU, held until the process
  * ends), which is why the image is limited to RDR_NOALLOC_MAX_PIXELS pixels (RDR_ERR_CAPACITY beyond that).
+ * A second limit applies to very narrow or very tall images: mip l is max(1, width >> l) x max(1, height >> l), so
+ * the six mips of e.g. a 2 x 1044480 image hold more than 4/3 of mip 0. The six mips (each rounded up to a multiple
+ * of four texels) plus second copies of mips 3 and 4 must fit 1.5 x RDR_NOALLOC_MAX_PIXELS texels, else
+ * RDR_ERR_CAPACITY; any image with both sides >= 32 and at most RDR_NOALLOC_MAX_PIXELS pixels fits.
  *   hdr_rgba16f_device  width*height RGBA16F pixels in device memory, 16-byte aligned (the colour attachment as is)
  *   out_rgba8_device    width*height RGBA8 pixels in device memory, 8-byte aligned
  *   out_avg_device      one float in device memory: the average log-luminance of the centre 256x256 window

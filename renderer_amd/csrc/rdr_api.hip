@@ -241,6 +241,7 @@ struct rdr_ctx {
     struct PendingFrame { bool on = false; rdr_frame_stats host{}; } pending[RDR_FRAME_SLOTS];
     uint64_t frames = 0;           // frames enqueued so far
     int slot = 0;                  // frame slot of the frame being enqueued (frames enqueued before it, modulo RDR_FRAME_SLOTS)
+    bool frame_claimed = false;    // the current rdr_render_frame call got as far as taking `slot` and a frame index for its frame
     bool tail_split = true;        // resolve and blended pass on the tail stream (RDR_TAIL_ON_SHADING_STREAM=1: on the shading stream)
     int lag = 1;                   // a call returns once the frame `lag` calls back has finished and been picked up (RDR_FRAMES_IN_FLIGHT - 1)
     hipEvent_t ev_sets[RDR_FRAME_SLOTS][10] = {};
@@ -960,8 +961,11 @@ int point_shadow_views(rdr_ctx* c, vec3 camera_pos, Batch& dynamic_batch) {
         refreshed.push_back(i);
     }
     if (!sb.views.empty()) {
+        // d_point_static exists once: the previous frame's rasteriser of the faces with moving meshes (stream2, in front of
+        // that frame's shading) may still be reading the static faces this batch is about to overwrite
+        if (c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[prev_slot(c)], 0));
         RDR_TRY(raster_batch(c, sb));
-        if (c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_shaded[prev_slot(c)], 0));  // see raster_batch
+        // (the copies into the maps the shaders read come behind the same wait)
         for (uint32_t i : refreshed) {
             const size_t off = (size_t)c->lights[i].slot * 6 * face_px;
             HIP_TRY(hipMemcpyAsync(c->d_point_shadow.as<float>() + off, c->d_point_static.as<float>() + off, 6 * face_px * 4,
@@ -1216,7 +1220,8 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
                       &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
                       &c->d_counters, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
-                      &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1]};
+                      &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1],
+                      &c->d_prim_cull, &c->d_models, &c->d_cand, &c->d_draw_scratch};
     for (DevBuf* b : bufs) b->release();
     for (rdr_ctx::AltBuffers& a : c->alt) {
         DevBuf* alts[] = {&a.batch_tables, &a.frame, &a.shade_tris, &a.recs, &a.keys[0], &a.keys[1], &a.vals[0], &a.vals[1], &a.tile_start, &a.depth, &a.vis,
@@ -1224,7 +1229,7 @@ void rdr_destroy(rdr_ctx* c) {
         for (DevBuf* b : alts) b->release();
     }
     for (HostImage& img : c->images) img.pixels.release();
-    c->h_stage.release(); c->h_read.release(); c->h_palette.release();
+    c->h_stage.release(); c->h_read.release(); c->h_palette.release(); c->h_cull.release();
     for (int i = 0; i < 10 * RDR_FRAME_SLOTS; i++) if (c->ev_sets[i / 10][i % 10]) (void)hipEventDestroy(c->ev_sets[i / 10][i % 10]);
     if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1671,17 +1676,23 @@ int rdr_set_exposure_bias(rdr_ctx* c, float bias, float gamma) {
 static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8, int out_is_device, float* out_avg) {
     const double t_enter = host_now();
     c->host_wait_s = 0.0;
+    c->frame_claimed = false;
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t W = c->W, H = c->H, S = c->settings.msaa;
     const size_t n = (size_t)W * H;
     RDR_TRY(upload_scene(c));
     RDR_TRY(run_skinning(c));
     RDR_TRY(ensure_post_targets(c));
-    c->slot = (int)(c->frames % RDR_FRAME_SLOTS);
-    c->ev = c->ev_sets[c->slot];
-    if (c->pending[c->slot].on) {  // the last frame of this slot was never picked up: it has long finished
-        HIP_TRY(hipEventSynchronize(c->ev[5]));
-        harvest(c, c->slot);
+    {
+        const int slot = (int)(c->frames % RDR_FRAME_SLOTS);
+        if (c->pending[slot].on) {  // the last frame of this slot was never picked up: it has long finished
+            HIP_TRY(hipEventSynchronize(c->ev_sets[slot][5]));
+            harvest(c, slot);
+        }
+        // from here on `slot` is this frame's (rdr_render_frame's error path drops the frame in c->slot only then)
+        c->slot = slot;
+        c->ev = c->ev_sets[slot];
+        c->frame_claimed = true;
     }
     // this frame writes the buffer set the last frame of its slot used: the sets rotate, the oldest comes to the front
     for (int a = 0; a < RDR_FRAME_SLOTS - 1; a++) {
@@ -1962,10 +1973,12 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream3);
         (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream4);
         (void)hipGetLastError();
-        c->pending[c->slot].on = false;
+        // A frame that failed before it took its slot (upload, skinning, target allocation) leaves c->slot naming the
+        // frame before it, which is intact and is handed over like the other older ones.
+        if (c->frame_claimed) c->pending[c->slot].on = false;
         for (rdr_ctx::ShadowKey& k : c->cascades_key) k.valid = false;  // targets may be half written
         c->point_dynamic_key.valid = false;
-        for (int age = RDR_FRAME_SLOTS - 1; age >= 1; age--) harvest(c, (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS);
+        for (int age = RDR_FRAME_SLOTS - 1; age >= (c->frame_claimed ? 1 : 0); age--) harvest(c, (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS);
         c->err = keep;
     }
     return rc;
@@ -2174,7 +2187,8 @@ int rdr_post_process_noalloc(rdr_ctx* c, const void* hdr_rgba16f, uint32_t width
     }
     const size_t fin4_at = words + (((size_t)bw[3] * bh[3] + 3u) & ~(size_t)3u);
     if (fin4_at + (size_t)bw[4] * bh[4] > NOALLOC_BLOOM_WORDS)
-        return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: bloom chain larger than the scratch array");
+        return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: the six bloom mips of this image (every level at least one texel wide and high) need "
+                                         "more than 1.5 x RDR_NOALLOC_MAX_PIXELS texels; use rdr_post_process");
     // the same launches, in the same order, as enqueue_post
     uint32_t* mip[6];
     int mw[6], mh[6];

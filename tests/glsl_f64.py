@@ -5,8 +5,10 @@ Everything here is written from the GLSL text and the host lines cited next to e
 cube-map face selection, linear filtering, depth-compare sampling). Nothing here is derived from oracle/ or from
 the HIP kernels: the point is a second, independent reading of the same source, in numpy float64.
 
-Scope: fragments whose result does not hinge on an implementation choice. Texture LOD selection is avoided by using
-1x1 material textures, triangle edges and shadow-compare ties are masked out by the callers (`valid` masks).
+Scope: fragments whose result does not hinge on an implementation choice. Triangle edges and shadow-compare ties are
+masked out by the callers (`valid` masks). Mip-mapped material textures follow the Vulkan level-of-detail rules with
+the one choice this build states for both of its back ends: isotropic filtering, with the derivatives of uv taken as
+forward differences to the pixels at x + 1 and y + 1 on the fragment's own triangle.
 """
 import numpy as np
 
@@ -219,6 +221,105 @@ def shadow_compare_linear(depth_map, s, t, ref, eps=2e-6):
     return val, k00 & k10 & k01 & k11
 
 
+def wrap_repeat(i, n):
+    return np.mod(i, n)
+
+
+def bilinear_repeat(level, u, v):
+    """LINEAR filter with REPEAT addressing on one level [h, w, C] of already decoded float texels."""
+    h, w = level.shape[:2]
+    x, y = u * w - 0.5, v * h - 0.5
+    i0, j0 = np.floor(x), np.floor(y)
+    a, b = (x - i0)[..., None], (y - j0)[..., None]
+    i0, j0 = i0.astype(np.int64), j0.astype(np.int64)
+    c00, c10 = level[wrap_repeat(j0, h), wrap_repeat(i0, w)], level[wrap_repeat(j0, h), wrap_repeat(i0 + 1, w)]
+    c01, c11 = level[wrap_repeat(j0 + 1, h), wrap_repeat(i0, w)], level[wrap_repeat(j0 + 1, h), wrap_repeat(i0 + 1, w)]
+    return (1 - b) * ((1 - a) * c00 + a * c10) + b * ((1 - a) * c01 + a * c11)
+
+
+def decode_texels(u8, srgb):
+    """RGBA8 bytes -> float texels as the sampler sees them: sRGB images decode R, G, B before filtering (alpha is
+    always linear), UNORM images are byte / 255."""
+    t = np.asarray(u8, np.float64) / 255.0
+    if srgb:
+        t = t.copy()
+        t[..., :3] = srgb_to_linear(np.asarray(u8)[..., :3])
+    return t
+
+
+def texture_lod(levels, dudx, dvdx, dudy, dvdy):
+    """Vulkan 1.3 "Level-of-Detail Operation" for an isotropic sampler without bias or clamp: rho = the longer of the
+    two derivative vectors in texels of level 0, lambda = log2(rho), clamped to the chain."""
+    h0, w0 = levels[0].shape[:2]
+    rho = np.maximum(np.hypot(dudx * w0, dvdx * h0), np.hypot(dudy * w0, dvdy * h0))
+    with np.errstate(divide="ignore"):
+        lam = np.log2(rho)
+    return np.clip(lam, 0.0, len(levels) - 1.0)
+
+
+def texture_2d(levels, u, v, dudx, dvdx, dudy, dvdy):
+    """texture(sampler2D, uv) with mag/min LINEAR, mipmap mode LINEAR, REPEAT (VulkanRenderer.cpp:41): the two levels
+    around lambda, each filtered bilinearly, blended by the fraction. `levels`: decoded float texels per mip level.
+    Returns (value [n, C], lambda [n])."""
+    lam = texture_lod(levels, dudx, dvdx, dudy, dvdy)
+    l0 = np.floor(lam).astype(np.int64)
+    l1 = np.minimum(l0 + 1, len(levels) - 1)
+    f = (lam - l0)[..., None]
+    out = np.zeros(np.shape(u) + (levels[0].shape[-1],))
+    for lv in range(len(levels)):
+        m0, m1 = l0 == lv, l1 == lv
+        if not (m0.any() or m1.any()):
+            continue
+        val = bilinear_repeat(levels[lv], u, v)
+        out = out + np.where(m0[..., None], (1 - f) * val, 0.0) + np.where(m1[..., None], f * val, 0.0)
+    return out, lam
+
+
+def blit_linear(src_u8, dw, dh, srgb):
+    """vkCmdBlitImage with VK_FILTER_LINEAR from a whole level to the whole next one (VulkanRenderer.cpp:311-346):
+    destination texel (i, j) samples the source at ((i + 0.5) * sw / dw, (j + 0.5) * sh / dh) in unnormalised
+    coordinates with clamp-to-edge; sRGB formats filter in linear light and encode again. Returns the unrounded
+    result in units of one byte step, [dh, dw, 4] float64 (what the stored byte must round from)."""
+    sh, sw = src_u8.shape[:2]
+    t = decode_texels(src_u8, srgb)
+    i, j = np.meshgrid(np.arange(dw), np.arange(dh), indexing="xy")
+    x, y = (i + 0.5) * (sw / dw) - 0.5, (j + 0.5) * (sh / dh) - 0.5
+    i0, j0 = np.floor(x), np.floor(y)
+    a, b = (x - i0)[..., None], (y - j0)[..., None]
+    i0, j0 = i0.astype(np.int64), j0.astype(np.int64)
+    ci = lambda k: np.clip(k, 0, sw - 1)  # noqa: E731
+    cj = lambda k: np.clip(k, 0, sh - 1)  # noqa: E731
+    val = (1 - b) * ((1 - a) * t[cj(j0), ci(i0)] + a * t[cj(j0), ci(i0 + 1)]) + b * ((1 - a) * t[cj(j0 + 1), ci(i0)] + a * t[cj(j0 + 1), ci(i0 + 1)])
+    out = val * 255.0
+    if srgb:
+        rgb = np.clip(val[..., :3], 0.0, 1.0)
+        out[..., :3] = np.where(rgb <= 0.0031308, rgb * 12.92, 1.055 * rgb ** (1 / 2.4) - 0.055) * 255.0
+    return out
+
+
+def cube_shadow_compare(depth_cube, d, ref, eps=2e-6):
+    """texture(samplerCubeArrayShadow, vec4(d, layer), ref) for one layer: LINEAR filter, compare LESS_OR_EQUAL
+    (VulkanRendererShadow.cpp:73 is the one shadow sampler, used for both arrays). Face and (s, t) by the cube rules,
+    the four texels of the footprint (across face edges where it leaves the face: seamless cube maps) are each compared
+    with `ref`, the 0 / 1 results are filtered. depth_cube: [6, r, r]. Returns (value, robust): robust is False where a
+    comparison is decided by less than `eps` or the footprint touches a cube corner."""
+    cube = np.asarray(depth_cube, np.float64)[..., None]
+    r = cube.shape[1]
+    face, s, t = cube_face_coords(d)
+    u, v = s * r - 0.5, t * r - 0.5
+    i0, j0 = np.floor(u), np.floor(v)
+    a, b = u - i0, v - j0
+    i0, j0 = i0.astype(np.int64), j0.astype(np.int64)
+    res, ok = [], np.ones(np.shape(ref), bool)
+    for di, dj in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        dep, k = cube_fetch(cube, face, i0 + di, j0 + dj)
+        dep = dep[..., 0]
+        res.append((ref <= dep).astype(np.float64))
+        ok &= k & (np.abs(ref - dep) > eps)
+    val = (1 - b) * ((1 - a) * res[0] + a * res[1]) + b * ((1 - a) * res[2] + a * res[3])
+    return val, ok
+
+
 # ------------------------------------------------------------------ pbr.frag
 
 
@@ -251,7 +352,7 @@ def brdf(radiance, L, N, V, albedo, roughness, metallic, F0):  # pbr.frag:211-23
     ndf = distribution_ggx(N, H, roughness)
     g = geometry_smith(N, V, L, roughness)
     F = fresnel_schlick(np.maximum(dot(H, V), 0.0), F0)
-    kD = (1.0 - F) * (1.0 - metallic)
+    kD = (1.0 - F) * np.asarray(1.0 - metallic)[..., None]
     numerator = (ndf * g)[..., None] * F
     denominator = np.maximum(4.0 * np.maximum(dot(N, V), 1e-3) * np.maximum(dot(N, L), 1e-3), 1e-5)
     specular = numerator / denominator[..., None]
@@ -259,52 +360,89 @@ def brdf(radiance, L, N, V, albedo, roughness, metallic, F0):  # pbr.frag:211-23
     return (kD * albedo / PI + specular) * radiance * ndl[..., None]
 
 
+POINT_SHADOW_NEAR, POINT_SHADOW_FAR = 0.1, 100.0  # pbr.frag:90-91
+
+
+def material_samples(frag, mat):
+    """The five texture(sampler, uv) values of pbr.frag:95-108 for n fragments, [n, 4] each, decoded (sRGB for the base
+    colour only, main.cpp:138). A material either carries 1x1 texels (`albedo`, `normal`, ... as uint8[4]) or mip
+    chains (`chains`: name -> list of uint8 levels) sampled at the fragments' uv with their derivatives."""
+    n = frag["world"].shape[0]
+    names = ("albedo", "normal", "metal_rough", "ao_tex", "emissive_tex")
+    out = {}
+    for name in names:
+        srgb = name == "albedo"
+        if mat.get("chains"):
+            levels = [decode_texels(lv, srgb) for lv in mat["chains"][name]]
+            out[name], _ = texture_2d(levels, frag["uv"][:, 0], frag["uv"][:, 1], frag["duvdx"][:, 0], frag["duvdx"][:, 1],
+                                      frag["duvdy"][:, 0], frag["duvdy"][:, 1])
+        else:
+            out[name] = np.broadcast_to(decode_texels(np.asarray(mat[name], np.uint8), srgb), (n, 4))
+    return out
+
+
 def pbr_frag(frag, mat, scene):
     """pbr.frag:93-209 for n fragments.
 
     frag: dict of interpolated vertex outputs, each [n, ...]: world (3), normal (3), tangent (3), bitangent (3),
-          ls (n_cascades, 3) = directionalLightSpaceCoords.
-    mat:  dict: base_color (4), emissive (3), metallic, roughness, ao, alpha_mode, alpha_cutoff and the five texel
-          values of its 1x1 textures as uint8[4]: albedo (sRGB), normal, metal_rough, ao_tex, emissive_tex.
-    scene: dict: cam (3), point_lights [(pos, intensity)] (no shadow maps), dir_direction (3), dir_intensity (3),
+          ls (n_cascades, 3) = directionalLightSpaceCoords; for mip-mapped materials also uv (2) and its forward
+          differences duvdx, duvdy (2 each).
+    mat:  dict: base_color (4), emissive (3), metallic, roughness, ao, alpha_mode, alpha_cutoff and its five textures
+          (see material_samples).
+    scene: dict: cam (3), point_lights [(pos, intensity, cube)] where cube is None for a light without a shadow map
+          and its six depth faces [6, r, r] otherwise, dir_direction (3), dir_intensity (3),
           cascades: list of depth maps, prefiltered: list of cube levels, irradiance: cube, lut: uint8 [h, w, >=2].
-    Returns (rgba [n, 4], robust [n])."""
+    Returns (rgba [n, 4], robust [n], info) with info["point_shadow"][i] = the shadow factor of light i per fragment
+    (NaN where the light was skipped before its look-up)."""
     n = frag["world"].shape[0]
     robust = np.ones(n, bool)
-    tex_albedo = np.concatenate([srgb_to_linear(mat["albedo"][:3]), [mat["albedo"][3] / 255.0]])
-    albedo = tex_albedo * np.asarray(mat["base_color"], np.float64)                         # :95
-    if mat["alpha_mode"] == 1 and albedo[3] < mat["alpha_cutoff"]:                          # :96-99
-        return np.zeros((n, 4)), robust
-    mr = np.asarray(mat["metal_rough"], np.float64) / 255.0
-    metallic = float(np.clip(mr[2] * mat["metallic"], 0.0, 1.0))                            # :100-101
-    roughness = float(np.clip(mr[1] * mat["roughness"], 0.05, 1.0))                         # :102
-    ao = mat["ao_tex"][0] / 255.0 * mat["ao"]                                               # :103
-    emissive = np.asarray(mat["emissive_tex"][:3], np.float64) / 255.0 * np.asarray(mat["emissive"], np.float64)  # :104
+    tex = material_samples(frag, mat)
+    albedo = tex["albedo"] * np.asarray(mat["base_color"], np.float64)                      # :95
+    masked = np.zeros(n, bool)
+    if mat["alpha_mode"] == 1:                                                              # :96-99
+        masked = albedo[:, 3] < mat["alpha_cutoff"]
+        robust &= np.abs(albedo[:, 3] - mat["alpha_cutoff"]) > 1e-4
+    metallic = np.clip(tex["metal_rough"][:, 2] * mat["metallic"], 0.0, 1.0)                # :100-101
+    roughness = np.clip(tex["metal_rough"][:, 1] * mat["roughness"], 0.05, 1.0)             # :102
+    ao = tex["ao_tex"][:, 0] * mat["ao"]                                                    # :103
+    emissive = tex["emissive_tex"][:, :3] * np.asarray(mat["emissive"], np.float64)         # :104
     T, Bt, Nn = normalize(frag["tangent"]), normalize(frag["bitangent"]), normalize(frag["normal"])  # :106
-    nt = np.asarray(mat["normal"][:3], np.float64) / 255.0 * 2.0 - 1.0                      # :108-109
-    N = normalize(T * nt[0] + Bt * nt[1] + Nn * nt[2])                                      # :110
+    nt = tex["normal"][:, :3] * 2.0 - 1.0                                                   # :108-109
+    N = normalize(T * nt[:, 0:1] + Bt * nt[:, 1:2] + Nn * nt[:, 2:3])                       # :110
     P = frag["world"]
     V = normalize(np.asarray(scene["cam"], np.float64) - P)                                 # :112
     I = -V
     Rv = I - 2.0 * dot(N, I)[..., None] * N                                                 # :114 reflect(-V, N)
-    F0 = 0.04 * (1.0 - metallic) + albedo[:3] * metallic                                    # :116-117 mix
-    F0 = np.broadcast_to(F0, (n, 3))
-    alb = np.broadcast_to(albedo[:3], (n, 3))
+    alb = albedo[:, :3]
+    F0 = 0.04 * (1.0 - metallic)[:, None] + alb * metallic[:, None]                         # :116-117 mix
     Lo = np.zeros((n, 3))
-    for lpos, lint in scene["point_lights"]:                                                # :123-160
-        lpos, lint = np.asarray(lpos, np.float64), np.asarray(lint, np.float64)
+    info = {"point_shadow": []}
+    for light in scene["point_lights"]:                                                     # :123-160
+        lpos, lint = np.asarray(light[0], np.float64), np.asarray(light[1], np.float64)
+        cube = light[2] if len(light) > 2 else None
         d = np.sqrt(np.sum((lpos - P) ** 2, -1))
         radiance = lint / (d * d)[..., None]
         peak = radiance.max(-1)
         on = peak > 1e-3                                                                    # :133
         robust &= np.abs(peak - 1e-3) > 1e-6
-        L = lpos - P                                                                        # no shadow map: L stays un-normalised (:157-158)
-        Lo += np.where(on[..., None], brdf(radiance, L, N, V, alb, roughness, metallic, F0), 0.0)
+        L = lpos - P                                                                        # :137
+        if cube is None:                                                                    # :157-158: L stays un-normalised
+            Lo += np.where(on[..., None], brdf(radiance, L, N, V, alb, roughness, metallic, F0), 0.0)
+            info["point_shadow"].append(np.full(n, np.nan))
+            continue
+        light_depth = np.abs(L).max(-1) - 0.05                                              # :139-141
+        far, near = POINT_SHADOW_FAR, POINT_SHADOW_NEAR
+        light_depth = (far - far * near / light_depth) / (far - near)                       # :143
+        shadow, ok = cube_shadow_compare(cube, -L, light_depth)                             # :149
+        lit = on & ~(shadow < 1e-3)                                                         # :151-152
+        robust &= ~on | (ok & (np.abs(shadow - 1e-3) > 1e-6))
+        Ln = normalize(L)                                                                   # :154
+        Lo += np.where(lit[..., None], shadow[..., None] * brdf(radiance, Ln, N, V, alb, roughness, metallic, F0), 0.0)  # :155
+        info["point_shadow"].append(np.where(on, shadow, np.nan))
     if scene.get("dir_direction") is not None:                                              # :163-183
         ls = frag["ls"]
         nc = ls.shape[1]
         split = np.full(n, nc)
-        coords = ls[:, 0].copy()
         for k in range(nc - 1, -1, -1):  # first cascade (lowest k) that contains the point wins
             c = ls[:, k]
             lo_, hi_ = np.minimum(c[:, 0], c[:, 1]), np.maximum(c[:, 0], c[:, 1])
@@ -329,18 +467,20 @@ def pbr_frag(frag, mat, scene):
     if scene.get("prefiltered") is not None:                                                # :186-200
         ndv = np.maximum(dot(N, V), 1e-3)
         levels = scene["prefiltered"]
-        spec, ok1 = cube_sample_lod(levels, Rv, np.full(n, roughness * len(levels)))
-        lut = texture_2d_repeat(scene["lut"], ndv, np.full(n, roughness))
+        spec, ok1 = cube_sample_lod(levels, Rv, roughness * len(levels))
+        lut = texture_2d_repeat(scene["lut"], ndv, roughness)
         F = fresnel_schlick(ndv, F0)
-        kD = (1.0 - F) * (1.0 - metallic)
+        kD = (1.0 - F) * (1.0 - metallic)[:, None]
         spec = spec * (F * lut[..., 0:1] + lut[..., 1:2])
         irr, ok2 = cube_sample(scene["irradiance"], N)
         diffuse = kD * irr * alb
-        Lo += (diffuse + spec) * ao
+        Lo += (diffuse + spec) * ao[:, None]
         robust &= ok1 & ok2
     color = np.minimum(Lo + emissive, 10.0)                                                 # :202-203
-    alpha = 1.0 if mat["alpha_mode"] == 1 else albedo[3]                                    # :205-208
-    return np.concatenate([color, np.full((n, 1), alpha)], -1), robust
+    alpha = np.ones(n) if mat["alpha_mode"] == 1 else albedo[:, 3]                          # :205-208
+    rgba = np.concatenate([color, alpha[:, None]], -1)
+    rgba = np.where(masked[:, None], 0.0, rgba)                                             # :97: outColor = vec4(0)
+    return rgba, robust, info
 
 
 # ------------------------------------------------------------------ env.vert + env.frag

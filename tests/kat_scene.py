@@ -2,10 +2,17 @@
 the answers out: basic.vert per vertex, Vulkan rasterisation at pixel centres, pbr.frag per fragment, env.frag for
 the background, the blend equation of the reference's "blend" pipeline for MASK / BLEND primitives.
 
-Material textures are 1x1, so sampling them involves no filtering or LOD choice. What the answer takes from the
-library under test, read back through the C ABI, is only what other known-answer tests pin on their own: the packed
-environment cubes (bake tests in test_shading_kat.py), the cascade matrices and the cascade depth maps (coverage /
-depth tests in test_oracle_kat.py).
+Two variants. "base": material textures are 1x1 (no filtering or LOD choice), five point lights without shadow maps.
+"detail": mip-mapped REPEAT textures of 128^2, 64^2 and a ragged 96x40 (several levels of minification on the ground,
+magnification on the box), a MASK card with a textured alpha, and point lights that cast shadows - two static
+occluders and a moving one - so that pbr.frag:136-155 (the cube-shadow reference depth, the look-up at -L, the
+normalised L) has known answers too.
+
+What the answer takes from the library under test, read back through the C ABI, is only what other known-answer tests
+pin on their own: the packed environment cubes (bake tests in test_shading_kat.py), the cascade matrices and the depth
+maps of cascades and cube faces (coverage / depth tests in test_oracle_kat.py; where the cube faces put their shadows is
+checked against the scene's geometry in test_shading_kat.py), and the mip levels of the images (checked there against
+the float64 blit before they are used).
 """
 import os
 
@@ -44,8 +51,8 @@ def constant_environment(res, colour):
 
 
 class KatPrim:
-    def __init__(self, geo, model, mat):
-        self.geo, self.model, self.mat = geo, np.asarray(model, np.float64), mat
+    def __init__(self, geo, model, mat, dynamic=False):
+        self.geo, self.model, self.mat, self.dynamic = geo, np.asarray(model, np.float64), mat, dynamic
 
 
 def _mat(albedo, normal, metal_rough, ao_tex, emissive_tex, base_color=(1, 1, 1, 1), emissive=(0, 0, 0), metallic=1.0, roughness=1.0,
@@ -74,8 +81,49 @@ def directional_light():
     return (d[0], (4.0, 3.0, 2.0), d[2])
 
 
-def prims():
+# "detail" variant: (position, intensity, casts shadows). The first two cast: one high above the boxes (their shadows fall
+# on the ground inside its -Y face), one low beside them (long shadows across several faces); the third has no map.
+DETAIL_LIGHTS = [((0.8, 5.0, -3.2), (60.0, 50.0, 40.0), True), ((-4.5, 3.2, -1.0), (36.0, 48.0, 60.0), True),
+                 ((3.0, 2.0, 2.0), (10.0, 12.0, 8.0), False)]
+
+
+def _chain_images(size, seed, crop=None, **kw):
+    imgs = scenes.material_images(size, seed, **kw)
+    if crop is not None:
+        imgs = tuple(np.ascontiguousarray(i[:crop[1], :crop[0]]) for i in imgs)
+    return dict(zip(("albedo", "normal", "metal_rough", "ao_tex", "emissive_tex"), imgs))
+
+
+def detail_prims():
+    """Opaque primitives, then MASK / BLEND ones, of the "detail" variant. `images` holds level 0 of the five textures;
+    the chains are read back from the renderer (build() stores the image ids)."""
+    def mat(images, **kw):
+        m = _mat((0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), **kw)
+        m["images"] = images
+        return m
+    ground = KatPrim(scenes.plane(30, 30, 1, 1, uv_scale=24.0), scenes.translation(0, 0, -12) @ G.rotate(0.1, 2) @ SCALE,
+                     mat(_chain_images(128, 501, tint=(0.9, 0.8, 0.7)), base_color=(0.9, 0.8, 0.7, 1.0), emissive=(0.5, 0.25, 0.125),
+                         metallic=0.9, roughness=0.8, ao=0.9))
+    box = KatPrim(scenes.box(1.5, 1.0, 1.5, 1, uv_scale=0.3), scenes.translation(0.5, 2.0, -3.0) @ G.rotate(0.4, 1),
+                  mat(_chain_images(64, 511, tint=(0.6, 0.9, 0.7), metal_fraction=0.6), metallic=1.0, roughness=0.7))
+    wall = KatPrim(scenes.plane(3, 2, 1, 1, uv_scale=3.0), scenes.translation(-3.0, 1.6, -2.5) @ G.rotate(np.pi / 2 - 0.2, 0) @ G.rotate(0.3, 2),
+                   mat(_chain_images(128, 521, crop=(96, 40), tint=(0.5, 0.7, 1.0)), base_color=(0.6, 0.8, 0.9, 1.0), metallic=0.35, roughness=0.5))
+    # the moving box mixes image sizes inside one material (normal and metal-rough maps of 32^2 beside 64^2 ones)
+    mixed = dict(_chain_images(64, 531, tint=(1.0, 0.6, 0.5)))
+    small = _chain_images(32, 551)
+    mixed["normal"], mixed["metal_rough"] = small["normal"], small["metal_rough"]
+    mover = KatPrim(scenes.box(0.8, 0.6, 0.8, 1), scenes.translation(2.2, 1.3, -4.5) @ G.rotate(-0.3, 1),
+                    mat(mixed, metallic=0.2, roughness=0.6), dynamic=True)
+    alpha = scenes.value_noise(64, 77, octaves=2, base=4)
+    card = KatPrim(scenes.plane(1.6, 1.6, 1, 1, uv_scale=1.5), scenes.translation(3.0, 1.2, -1.0) @ G.rotate(np.pi / 2, 0),
+                   mat(_chain_images(64, 541, tint=(0.5, 1.0, 0.5), alpha=(0.2 + 0.6 * alpha).astype(np.float32)), alpha_mode=B.ALPHA_MASK, alpha_cutoff=0.5))
+    return [ground, box, wall, mover], [card]
+
+
+def prims(variant="base"):
     """The opaque primitives first, then the MASK / BLEND ones."""
+    if variant == "detail":
+        return detail_prims()
     ground = KatPrim(scenes.plane(30, 30, 1, 1), scenes.translation(0, 0, -12) @ G.rotate(0.1, 2) @ SCALE,
                      _mat((200, 150, 100, 255), (150, 110, 240, 255), (0, 180, 60, 255), (210, 0, 0, 255), (30, 60, 90, 255),
                           base_color=(0.9, 0.8, 0.7, 1.0), emissive=(0.5, 0.25, 0.125), metallic=0.9, roughness=0.8, ao=0.9))
@@ -97,22 +145,69 @@ def prims():
     return [ground, box, wall], [mask_pass, mask_fail, blend]
 
 
-def build(r, env_faces, lut=None, with_meshes=True):
-    """Issues the API calls for the scene on renderer `r` (any back end behind the C ABI)."""
+TEXTURE_NAMES = ("albedo", "normal", "metal_rough", "ao_tex", "emissive_tex")
+TEXTURE_FORMATS = (B.FORMAT_R8G8B8A8_SRGB, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM)
+
+
+def build(r, env_faces, lut=None, with_meshes=True, variant="base"):
+    """Issues the API calls for the scene on renderer `r` (any back end behind the C ABI). Returns the primitives
+    (opaque, blended); in the "detail" variant each material carries the ids of its five images under "image_ids"."""
+    opaque, blended = prims(variant)
     if with_meshes:
-        opaque, blended = prims()
         for p in opaque + blended:
             m = p.mat
-            fmts = (B.FORMAT_R8G8B8A8_SRGB, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM, B.FORMAT_R8G8B8A8_UNORM)
-            texels = (m["albedo"], m["normal"], m["metal_rough"], m["ao_tex"], m["emissive_tex"])
-            tex = [r.make_texture(r.load_image(np.asarray(t, np.uint8).reshape(1, 1, 4), f)) for t, f in zip(texels, fmts)]
+            if "images" in m:
+                m["image_ids"] = [r.load_image(m["images"][name], f) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
+                tex = [r.make_texture(i) for i in m["image_ids"]]
+            else:
+                tex = [r.make_texture(r.load_image(np.asarray(m[name], np.uint8).reshape(1, 1, 4), f)) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
             material = scenes.make_material(tex, base_color=m["base_color"], emissive=m["emissive"], metallic=m["metallic"],
                                             roughness=m["roughness"], ao=m["ao"], alpha_mode=m["alpha_mode"], alpha_cutoff=m["alpha_cutoff"])
-            r.add_mesh([scenes.upload_primitive(r, p.geo, material)], model=p.model.T)
+            r.add_mesh([scenes.upload_primitive(r, p.geo, material)], model=p.model.T, is_static=not p.dynamic)
     r.set_brdf_lut(reference_lut() if lut is None else lut)
     r.set_environment_map(env_faces)
     r.set_camera(position=CAMERA["position"], euler=CAMERA["euler"], near=CAMERA["near"], far=CAMERA["far"], fov_or_height=CAMERA["fov"])
-    r.set_lights([(p, i, False) for p, i in POINT_LIGHTS], directional_light())
+    r.set_lights(DETAIL_LIGHTS if variant == "detail" else [(p, i, False) for p, i in POINT_LIGHTS], directional_light())
+    return opaque, blended
+
+
+def read_chains(r, opaque, blended):
+    """Reads the mip chains of the "detail" materials back and checks every level against the float64 blit of the level
+    above it (vkCmdBlitImage LINEAR, VulkanRenderer.cpp:311-346): the stored byte must be one of the two codes next to
+    the exact value, and off the nearest by more than a rounding tie's worth in under 1 % of the texels. Returns the
+    number of levels checked."""
+    n_levels = 0
+    for p in opaque + blended:
+        m = p.mat
+        if "image_ids" not in m:
+            continue
+        m["chains"] = {}
+        for name, image, fmt in zip(TEXTURE_NAMES, m["image_ids"], TEXTURE_FORMATS):
+            h, w = m["images"][name].shape[:2]
+            count = int(np.floor(np.log2(max(w, h)))) + 1   # VulkanRenderer.cpp:311-315
+            levels = [r.read_image_level(image, l) for l in range(count)]
+            assert np.array_equal(levels[0], m["images"][name])
+            for l in range(1, count):
+                assert levels[l].shape[:2] == (max(1, h >> l), max(1, w >> l))
+                exact = G.blit_linear(levels[l - 1], levels[l].shape[1], levels[l].shape[0], fmt == B.FORMAT_R8G8B8A8_SRGB)
+                err = np.abs(levels[l].astype(np.float64) - exact)
+                assert err.max() < 1.0, (name, l, err.max())
+                assert (err > 0.5 + 1e-3).mean() < 0.01, (name, l)
+                n_levels += 1
+            m["chains"][name] = levels
+    return n_levels
+
+
+def point_light_cubes(r, lights, camera_position):
+    """Slot assignment of VulkanRendererShadow.cpp:281-296 (the shadow-casting lights nearest the camera first, stable)
+    and the six depth faces of each slotted light, read back. Returns one entry per light: [6, res, res] or None."""
+    casters = [i for i, l in enumerate(lights) if l[2]]
+    eye = np.asarray(camera_position, np.float64)
+    casters.sort(key=lambda i: np.linalg.norm(np.asarray(lights[i][0], np.float64) - eye))
+    cubes = [None] * len(lights)
+    for slot, i in enumerate(casters[:r.settings.point_shadow_map_count]):
+        cubes[i] = np.stack([r.read_point_shadow(slot, f) for f in range(6)]).astype(np.float64)
+    return cubes
 
 
 def vertex_stage(p, view_proj, cascade_vps):
@@ -127,7 +222,8 @@ def vertex_stage(p, view_proj, cascade_vps):
     nrm, tan = g.nrm.astype(np.float64), g.tan.astype(np.float64)
     bit = np.cross(nrm, tan[:, :3]) * tan[:, 3:4]  # main.cpp:93: bitangent = cross(normal, tangent.xyz) * tangent.w
     R = M[:3, :3]
-    out = dict(clip=clip, world=world, normal=G.normalize(nrm @ R.T), tangent=G.normalize(tan[:, :3] @ R.T), bitangent=G.normalize(bit @ R.T))
+    out = dict(clip=clip, world=world, normal=G.normalize(nrm @ R.T), tangent=G.normalize(tan[:, :3] @ R.T), bitangent=G.normalize(bit @ R.T),
+               uv=g.uv.astype(np.float64))
     ls = []
     for vp in cascade_vps:
         lsp = np.concatenate([world, np.ones((n, 1))], -1) @ vp.T
@@ -136,9 +232,12 @@ def vertex_stage(p, view_proj, cascade_vps):
     return out
 
 
-def expected_hdr(r, W, H, margin):
+def expected_hdr(r, W, H, margin, variant="base", built=None, details=None):
     """The RGBA16F colour image the reference's main pass leaves for the scene of build(), in float64, and the mask of
-    pixels whose value does not depend on an edge rule, a compare tie or a cube corner."""
+    pixels whose value does not depend on an edge rule, a compare tie or a cube corner. `built`: what build() returned
+    (needed for the "detail" variant, whose materials carry image ids). `details`, if a dict, receives per-pixel
+    images for further checks: lambda of the albedo texture, the shadow factors of the point lights, world position,
+    primitive index."""
     cam = CAMERA
     aspect = float(np.float32(W) / np.float32(H))
     view_proj = G.camera_view_proj(cam["position"], cam["euler"], cam["near"], cam["far"], cam["fov"], aspect)
@@ -146,31 +245,56 @@ def expected_hdr(r, W, H, margin):
     n_casc = r.settings.directional_shadow_cascade_levels
     cascade_vps = [vps[i].T.astype(np.float64) for i in range(n_casc)]
     dl = directional_light()
-    scene = dict(cam=cam["position"], point_lights=POINT_LIGHTS, dir_direction=G.quat_rotate(dl[2], (0.0, 0.0, 1.0)),
+    if variant == "detail":
+        cubes = point_light_cubes(r, DETAIL_LIGHTS, cam["position"])
+        point_lights = [(l[0], l[1], cube) for l, cube in zip(DETAIL_LIGHTS, cubes)]
+    else:
+        point_lights = [(p, i, None) for p, i in POINT_LIGHTS]
+    scene = dict(cam=cam["position"], point_lights=point_lights, dir_direction=G.quat_rotate(dl[2], (0.0, 0.0, 1.0)),
                  dir_intensity=dl[1], cascades=[r.read_directional_shadow(i) for i in range(n_casc)],
                  prefiltered=[r.read_env_cube(2, l).astype(np.float64) for l in range(10)],
                  irradiance=r.read_env_cube(1).astype(np.float64), lut=reference_lut())
-    opaque, blended = prims()
+    opaque, blended = built if built is not None else prims(variant)
+    if variant == "detail":
+        read_chains(r, opaque, blended)
     colour = np.zeros((H, W, 4))
     valid = np.ones((H, W), bool)
+    if details is not None:
+        details.update(lod=np.full((H, W), np.nan), world=np.full((H, W, 3), np.nan), prim=np.full((H, W), -1),
+                       point_shadow=np.full((len(point_lights), H, W), np.nan))
     depth = np.ones((H, W))
     # ---- background: the skybox covers every pixel the opaque pass left at depth 1 (VulkanRenderer.cpp:1054-1057)
     xn, yn = np.meshgrid((np.arange(W) + 0.5) / W * 2 - 1, (np.arange(H) + 0.5) / H * 2 - 1, indexing="xy")
     sky, sky_ok = G.env_frag(r.read_env_cube(0).astype(np.float64), np.linalg.inv(view_proj), xn, yn)
 
-    def shade_prim(p, vs, tri_inside, lam, tri_index):
+    def shade_prim(p, vs, tri_inside, lam, tri_index, prim_index=-1):
         """pbr.frag for the pixels of `tri_inside` [H, W] of triangle `tri_index`."""
         ys, xs = np.nonzero(tri_inside)
         ids = p.geo.idx.reshape(-1, 3)[tri_index]
         l = lam[ys, xs]
-        frag = {k: np.einsum("nv,v...->n...", l, vs[k][ids]) for k in ("world", "normal", "tangent", "bitangent", "ls")}
-        rgba, robust = G.pbr_frag(frag, p.mat, scene)
+        frag = {k: np.einsum("nv,v...->n...", l, vs[k][ids]) for k in ("world", "normal", "tangent", "bitangent", "ls", "uv")}
+        # forward differences of uv to the pixels at x + 1 and y + 1, on this triangle's plane (it need not cover them)
+        have_next = (xs + 1 < W) & (ys + 1 < H)
+        lx, ly = lam[ys, np.minimum(xs + 1, W - 1)], lam[np.minimum(ys + 1, H - 1), xs]
+        frag["duvdx"] = np.einsum("nv,v...->n...", lx, vs["uv"][ids]) - frag["uv"]
+        frag["duvdy"] = np.einsum("nv,v...->n...", ly, vs["uv"][ids]) - frag["uv"]
+        rgba, robust, info = G.pbr_frag(frag, p.mat, scene)
+        if p.mat.get("chains"):
+            robust &= have_next
+        if details is not None and prim_index >= 0:
+            details["world"][ys, xs] = frag["world"]
+            details["prim"][ys, xs] = prim_index
+            for i, sh in enumerate(info["point_shadow"]):
+                details["point_shadow"][i][ys, xs] = sh
+            if p.mat.get("chains"):
+                levels = [G.decode_texels(lv, True) for lv in p.mat["chains"]["albedo"]]
+                details["lod"][ys, xs] = G.texture_lod(levels, frag["duvdx"][:, 0], frag["duvdx"][:, 1], frag["duvdy"][:, 0], frag["duvdy"][:, 1])
         return ys, xs, rgba, robust
 
     # ---- opaque pass: depth LESS, nearest fragment wins (order does not matter away from ties)
     opaque_colour = np.zeros((H, W, 4))
     covered = np.zeros((H, W), bool)
-    for p in opaque:
+    for prim_index, p in enumerate(opaque):
         vs = vertex_stage(p, view_proj, cascade_vps)
         tris = vs["clip"][p.geo.idx.reshape(-1, 3)]
         assert np.all(tris[..., 3] > 2 * cam["near"]), "the scene must stay clear of the near plane"
@@ -181,7 +305,7 @@ def expected_hdr(r, W, H, margin):
             valid &= ~(inside[k] & (np.abs(z[k] - depth) < 1e-6))
             if not win.any():
                 continue
-            ys, xs, rgba, robust = shade_prim(p, vs, win, lam[k], k)
+            ys, xs, rgba, robust = shade_prim(p, vs, win, lam[k], k, prim_index)
             opaque_colour[ys, xs] = rgba
             valid[ys, xs] &= robust
             depth[win] = z[k][win]

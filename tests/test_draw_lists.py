@@ -122,3 +122,31 @@ def test_unchanged_shadow_views_are_not_rendered_again(orc_capi, hip_capi):
     assert reused[4] == 0 and reused[5] == 12            # the sphere moved; one frame later the faces are current again
     assert reused[6] == 12                               # camera moved: cascades redrawn, faces kept
     assert views[3] == 1 and views[0] > views[1] == views[2] > views[3]
+
+
+def test_slot_changes_between_frames_in_flight(hip_capi):
+    """The camera jumps between two spots every frame, so that the two shadow-casting lights swap cube slots and their
+    static faces are rendered again each time, while the frame before - whose faces with the moving sphere start from
+    those same static faces - may still be on the GPU. Frames kept in flight (device destinations, no wait in between)
+    must equal the same frames rendered one at a time."""
+    import torch
+    W, H, n = 320, 180, 10
+    spots = [dict(position=(2.4, 1.7, 4.0), euler=(-0.2, 0.3, 0.0)), dict(position=(-3.0, 1.6, 4.2), euler=(-0.2, -0.35, 0.0))]
+    rp = Renderer(hip_capi, W, H, default_settings(**SETTINGS))
+    rs = Renderer(hip_capi, W, H, default_settings(**SETTINGS))
+    ip, isr = scenes.small_scene(rp), scenes.small_scene(rs)
+    dst = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(n)]
+    serial = []
+    for t in range(n):
+        for r, ids in ((rp, ip), (rs, isr)):
+            r.set_camera(**spots[t & 1])
+            r.set_mesh_transform(ids["sphere"], scenes.translation(0.1 * t, 0.9, 0.4).T)
+        rp.render_frame(device_ptr=dst[t].data_ptr(), **FRAME)
+        out, _ = rs.render_frame(**FRAME)
+        serial.append(out.copy())
+    rp.synchronize()
+    for t in range(n):
+        assert np.array_equal(dst[t].cpu().numpy(), serial[t]), f"frame {t}"
+    # the slots did change hands: the nearest light differs between the two spots
+    d = [[np.linalg.norm(np.subtract(l, s["position"])) for l in ((1.5, 2.2, 1.5), (-2.0, 1.8, 2.0))] for s in spots]
+    assert (d[0][0] < d[0][1]) != (d[1][0] < d[1][1])

@@ -45,6 +45,76 @@ def check_pbr(capi, msaa):
     return n_frag
 
 
+def _segment_hits_box(P, light, prim, grow):
+    """Does the segment from P [n, 3] to `light` pass through the box primitive `prim`, its faces moved outwards by
+    `grow` (inwards when negative)? Slab test in the box's own coordinates."""
+    inv = np.linalg.inv(prim.model)
+    lo, hi = prim.geo.pos.min(0).astype(np.float64) - grow, prim.geo.pos.max(0).astype(np.float64) + grow
+    a = np.concatenate([P, np.ones((P.shape[0], 1))], -1) @ inv.T
+    b = np.append(np.asarray(light, np.float64), 1.0) @ inv.T
+    o, d = a[:, :3], b[:3] - a[:, :3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0, t1 = (lo - o) / d, (hi - o) / d
+    tmin, tmax = np.minimum(t0, t1).max(-1), np.maximum(t0, t1).min(-1)
+    return (tmin <= tmax) & (tmax >= 0.0) & (tmin <= 1.0)
+
+
+def check_detail(capi, msaa):
+    """Mip-mapped textures and shadowed point lights (the "detail" variant of tests/kat_scene.py)."""
+    W, H = 240, 144
+    r = _renderer(capi, W, H, msaa)
+    built = K.build(r, K.linear_environment(32), variant="detail")
+    r.render_frame(exposure_mode=2, exposure=0.0)
+    got = r.read_hdr().astype(np.float64)
+    det = {}
+    want, valid = K.expected_hdr(r, W, H, margin=0.02 if msaa == 1 else 1.0, variant="detail", built=built, details=det)
+    opaque = built[0]
+    on_geometry = det["prim"] >= 0
+    n_frag = int((valid & on_geometry).sum())
+    assert n_frag >= 4000, f"only {n_frag} shaded fragments are pinned"
+    # ---- what the pinned fragments cover
+    lod = det["lod"]
+    n_minified = int((valid & (lod >= 3.0)).sum())
+    n_between = int((valid & (lod > 0.0) & (lod < 3.0)).sum())
+    n_magnified = int((valid & (lod == 0.0)).sum())
+    assert n_minified >= 500 and n_between >= 300 and n_magnified >= 300, (n_minified, n_between, n_magnified)
+    assert np.nanmax(np.where(valid, lod, np.nan)) >= 5.0, "the far ground reaches the small levels of its 128^2 chain"
+    sh = det["point_shadow"]  # [light, H, W]
+    casting = [i for i, l in enumerate(K.DETAIL_LIGHTS) if l[2]]
+    partly = np.zeros((H, W), bool)
+    fully = np.zeros((H, W), bool)
+    for i in casting:
+        partly |= (sh[i] > 1e-3) & (sh[i] < 1.0 - 1e-3)
+        fully |= sh[i] == 0.0
+    n_partly, n_fully = int((valid & partly).sum()), int((valid & fully).sum())
+    assert n_partly >= 100 and n_fully >= 500, (n_partly, n_fully)
+    # ---- where the cube faces put the shadows, against the geometry of the scene (not against any depth map): ground
+    # fragments whose line of sight to the light passes well inside one of the two boxes are in full shadow; those
+    # under the light (its -Y face, where the ground's depth is nearly constant over a texel) that clear every
+    # occluder by a wide margin are fully lit
+    ground = det["prim"] == 0
+    box, wall, mover = opaque[1], opaque[2], opaque[3]
+    ys, xs = np.nonzero(ground & valid)
+    P = det["world"][ys, xs]
+    for i in casting:
+        light = np.asarray(K.DETAIL_LIGHTS[i][0], np.float64)
+        s_i = sh[i][ys, xs]
+        umbra = _segment_hits_box(P, light, box, -0.2) | _segment_hits_box(P, light, mover, -0.2)
+        assert umbra.sum() >= 50 and np.all(s_i[umbra & ~np.isnan(s_i)] == 0.0), f"light {i}: umbra of the boxes"
+        wall_box = type("W", (), {})()
+        wall_box.model, wall_box.geo = wall.model, wall.geo
+        clear = ~(_segment_hits_box(P, light, box, 0.4) | _segment_hits_box(P, light, mover, 0.4) | _segment_hits_box(P, light, wall_box, 0.4))
+        L = light - P
+        under = np.abs(L[:, 1]) > 1.5 * np.maximum(np.abs(L[:, 0]), np.abs(L[:, 2]))
+        sel = clear & under & ~np.isnan(s_i)
+        if i == casting[0]:
+            assert sel.sum() >= 200
+        assert np.all(s_i[sel] == 1.0), f"light {i}: open ground under the light"
+    # ---- and the colours: 2^-11 from each of up to two RGBA16F roundings, float32 arithmetic on top
+    _assert_close(got, want, valid, rtol=1.5e-3, atol=2e-4, what=f"pbr.frag with mip-mapped textures and shadowed point lights, msaa {msaa}")
+    return dict(fragments=n_frag, minified=n_minified, magnified=n_magnified, partly_shadowed=n_partly, fully_shadowed=n_fully)
+
+
 def check_sky(capi):
     W, H = 64, 40
     r = _renderer(capi, W, H, 1)
@@ -131,10 +201,21 @@ def test_environment_bakes_known_answers(orc_capi):
     check_bakes(orc_capi)
 
 
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_mip_mapped_textures_and_shadowed_point_lights(orc_capi, msaa):
+    print(check_detail(orc_capi, msaa))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("msaa", [1, 4])
 def test_pbr_frag_known_answers_hip(hip_capi, msaa):
     check_pbr(hip_capi, msaa)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_mip_mapped_textures_and_shadowed_point_lights_hip(hip_capi, msaa):
+    print(check_detail(hip_capi, msaa))
 
 
 @pytest.mark.gpu
