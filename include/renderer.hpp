@@ -65,6 +65,8 @@ int RDR_ABI(set_camera)(rdr_ctx*, const rdr_camera*);
 int RDR_ABI(set_exposure_bias)(rdr_ctx*, float, float);
 int RDR_ABI(render_frame)(rdr_ctx*, const rdr_frame_params*, uint8_t*, int, float*);
 int RDR_ABI(get_frame_stats)(rdr_ctx*, rdr_frame_stats*);
+int RDR_ABI(wait_frame)(rdr_ctx*, uint64_t);
+int RDR_ABI(synchronize)(rdr_ctx*);
 }
 
 namespace hiprenderer {
@@ -649,6 +651,10 @@ public:
         const rdr_frame_params p = {fp.exposureMode, fp.deltaTime, fp.temporalLuminance, fp.exposure};
         check(RDR_ABI(render_frame)(ctx, &p, dst, dstIsDevice ? 1 : 0, avgLogLuminance), "renderFrame");
     }
+    // Frames rendered into device memory are only enqueued (up to two in flight, rdr.h): waitFrame(i) returns once the
+    // i-th frame of this renderer (counted from 1) is complete, synchronize() once everything enqueued is.
+    void waitFrame(uint64_t frameIndex) { check(RDR_ABI(wait_frame)(ctx, frameIndex), "waitFrame"); }
+    void synchronize() { check(RDR_ABI(synchronize)(ctx), "synchronize"); }
     rdr_frame_stats frameStats() {
         rdr_frame_stats s;
         check(RDR_ABI(get_frame_stats)(ctx, &s), "frameStats");

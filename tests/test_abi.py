@@ -164,3 +164,21 @@ def _check_resource_refusals(api):
 def test_settings_and_resources_the_hip_library_refuses(hip_capi):
     assert _refusals(hip_capi) == EXPECTED_REFUSALS
     _check_resource_refusals(hip_capi)
+
+
+def test_gather_library_exports_what_its_header_declares():
+    """include/rdr_gather.h (the multi-GPU exchange step for C / C++ hosts): renderer_amd/lib/librdr_gather.so loads
+    without a GPU (RCCL is only linked) and exports every function the header declares."""
+    import ctypes
+    text = open(os.path.join(ROOT, "include", "rdr_gather.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(rdr_gather_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["rdr_gather_all_floats", "rdr_gather_create", "rdr_gather_destroy", "rdr_gather_frames", "rdr_gather_last_error",
+                     "rdr_gather_make_id", "rdr_gather_wait"]
+    lib = ctypes.CDLL(os.path.join(ROOT, "renderer_amd", "lib", "librdr_gather.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+    # argument checks that need no device
+    assert lib.rdr_gather_make_id(None) == 1
+    out = ctypes.c_void_p()
+    assert lib.rdr_gather_create(None, 0, 1, 0, ctypes.byref(out)) == 1

@@ -160,3 +160,27 @@ def test_facade_program_on_the_hip_library(hip_capi, tmp_path):
     orc_frames, _ = run_binary(build_orc_binary(), tmp_path, "orc")
     for k in range(3):
         hp.assert_image_close(orc_frames[k], hip_frames[k])
+
+
+@pytest.mark.gpu
+def test_sharded_host_program_gathers_over_rccl(hip_capi, tmp_path):
+    """tests/cpp/shard_host.cpp: a C++ host that renders a frame batch rank by rank and brings the frames to rank 0 with
+    the grouped ncclSend / ncclRecv of include/rdr_gather.h, started as a fresh process per rank. One GPU here, so the
+    world is one rank: the communicator, the send-to-self group, the pipelined loop (frame k + 1 enqueued before frame
+    k is gathered) and the luminance all-gather all run; the frames must equal those of the same program rendering
+    one frame at a time without the gather library."""
+    exe = os.path.join(CPP, "shard_host_hip")
+    assert os.path.exists(exe), "tests/cpp/shard_host_hip is built by __graft_entry__.build()"
+    n = 7
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    serial = subprocess.run([exe, str(tmp_path / "serial.raw"), str(n), "0", "0", str(tmp_path / "unused")], check=True, capture_output=True,
+                            text=True, timeout=300, env=env)
+    shard = subprocess.run([exe, str(tmp_path / "shard.raw"), str(n), "1", "0", str(tmp_path / "id"), "0"], check=True, capture_output=True,
+                           text=True, timeout=300, env=env)
+    a = np.fromfile(tmp_path / "serial.raw", np.uint8).reshape(n, 96, 160, 4)
+    b = np.fromfile(tmp_path / "shard.raw", np.uint8).reshape(n, 96, 160, 4)
+    for k in range(n):
+        assert np.array_equal(a[k], b[k]), f"frame {k}"
+    assert len({a[k].tobytes() for k in range(n)}) == n and a[..., :3].std() > 10
+    lum = lambda text: [ln for ln in text.splitlines() if ln.startswith("luminance")]  # noqa: E731  (RCCL prints a banner of its own)
+    assert lum(serial.stdout) == lum(shard.stdout) and len(lum(serial.stdout)) == n

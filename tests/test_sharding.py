@@ -239,3 +239,67 @@ def test_frames_in_flight_with_changing_scene_state(hip_capi, in_flight, monkeyp
         got = host[k] if k in host else slots[k].cpu().numpy()
         assert np.array_equal(got, serial[k]), f"frame {k}"
     r2.close()
+
+
+def _nccl_world_of_one(port, out_dir, root):
+    """Child process: the branch bench.py --gpus N takes on every rank (torch.distributed "nccl" = RCCL, device staging
+    tensors, frames in flight, asynchronous gathers retired when their slot comes round again), with a world of one."""
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+
+    from renderer_amd import scenes
+    from renderer_amd.api import Renderer, default_settings, load_hip_capi
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        Wn, Hn, n = 320, 180, 10
+        r = Renderer(load_hip_capi(), Wn, Hn, default_settings(msaa=4, directional_shadow_map_resolution=512, point_shadow_map_resolution=128))
+        ids = scenes.small_scene(r)
+
+        def set_frame(rr, k):
+            rr.set_camera(position=(0.3 * k - 0.5, 1.2 + 0.1 * k, 4.0 - 0.2 * k), euler=(-0.1, 0.05 * k, 0.0))
+            rr.set_mesh_transform(ids["sphere"], scenes.translation(0.1 * k, 0.9, 0.4).T)
+
+        sh = sharding.FrameSharder(r, dist=dist, device="cuda:0", depth=4)
+        got = {}
+        lum = sh.run(n, set_frame, dict(exposure_mode=1, temporal_luminance=0.5), on_frame=lambda k, t: got.__setitem__(k, t.cpu().numpy().copy()))
+        table = sh.gather_luminance(n)
+        torch.cuda.synchronize()
+        assert sorted(got) == list(range(n)) and sh.frames_rendered == n
+        np.save(os.path.join(out_dir, "frames.npy"), np.stack([got[k] for k in range(n)]))
+        np.save(os.path.join(out_dir, "lum.npy"), np.array([lum[k] for k in range(n)], np.float32))
+        np.save(os.path.join(out_dir, "table.npy"), table)
+        # the same frames one at a time, in the same process
+        r2 = Renderer(load_hip_capi(), Wn, Hn, default_settings(msaa=4, directional_shadow_map_resolution=512, point_shadow_map_resolution=128))
+        ids2 = scenes.small_scene(r2)
+        serial, serial_lum = [], []
+        for k in range(n):
+            r2.set_camera(position=(0.3 * k - 0.5, 1.2 + 0.1 * k, 4.0 - 0.2 * k), euler=(-0.1, 0.05 * k, 0.0))
+            r2.set_mesh_transform(ids2["sphere"], scenes.translation(0.1 * k, 0.9, 0.4).T)
+            img, avg = r2.render_frame(exposure_mode=1, temporal_luminance=0.5)
+            serial.append(img.copy()); serial_lum.append(avg)
+        np.save(os.path.join(out_dir, "serial.npy"), np.stack(serial))
+        np.save(os.path.join(out_dir, "serial_lum.npy"), np.array(serial_lum, np.float32))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_branch_with_a_world_of_one(hip_capi, tmp_path):
+    """FrameSharder with the nccl backend and device tensors, in a fresh process (as every rank of bench.py --gpus N
+    is): RCCL work handles, the retire logic that orders the renderer's streams against the gather, four staging
+    slots over ten frames. Gathered frames must equal frame-by-frame rendering byte for byte."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); from tests.test_sharding import _nccl_world_of_one; _nccl_world_of_one(%d, %r, %r)"
+            % (ROOT, _free_port(), str(tmp_path), ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    frames, serial = np.load(tmp_path / "frames.npy"), np.load(tmp_path / "serial.npy")
+    for k in range(frames.shape[0]):
+        assert np.array_equal(frames[k], serial[k]), f"frame {k}"
+    assert len({f.tobytes() for f in frames}) == frames.shape[0]
+    assert np.array_equal(np.load(tmp_path / "lum.npy"), np.load(tmp_path / "serial_lum.npy"))
+    assert np.array_equal(np.load(tmp_path / "table.npy"), np.load(tmp_path / "lum.npy"))
