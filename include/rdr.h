@@ -292,6 +292,11 @@ int rdr_set_environment_equirect(rdr_ctx* ctx, const float* rgba32f, uint32_t wi
  * BRDF table (GGX importance sampling on the Hammersley points of envbakespecular.frag:17-53; R = scale, G = bias
  * of F0) and installs it like rdr_set_brdf_lut. Layout as the shipped file: column = NdotV, row 0 = roughness 1. */
 int rdr_generate_brdf_lut(rdr_ctx* ctx, uint32_t size, uint32_t samples);
+/* No counterpart in the reference (which times nothing, VulkanRenderer.cpp:1019-1023 aside). Device time in ms of the
+ * kernels of the last environment precompute on this context: out[0] panorama -> cube faces
+ * (rdr_set_environment_equirect), out[1] irradiance bake, out[2] GGX prefilter bake (ten levels), out[3] BRDF table
+ * (rdr_generate_brdf_lut); uploads and allocation are not in these numbers. HIP library only. */
+int rdr_get_precompute_ms(rdr_ctx* ctx, float out_ms[4]);
 /* renderer.camera() mutators (VulkanRenderer.h:108, Camera.h:35-54) collapsed
  * into one state upload. */
 int rdr_set_camera(rdr_ctx* ctx, const rdr_camera* camera);

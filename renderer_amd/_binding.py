@@ -134,6 +134,7 @@ SIGNATURES = {
 # entry points only the HIP library has (the CPU checker allocates nothing on a device to begin with)
 HIP_ONLY_SIGNATURES = {
     "post_process_noalloc": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_float, _VP, _VP, _VP]),
+    "get_precompute_ms": (C.c_int, [_VP, _FP]),
 }
 NOALLOC_MAX_PIXELS = 1920 * 1088
 

@@ -195,6 +195,12 @@ class Renderer:
     def generate_brdf_lut(self, size=400, samples=1024):
         self._check(self.api.generate_brdf_lut(self._ctx, int(size), int(samples)), "generate_brdf_lut")
 
+    def precompute_ms(self):
+        """Device time of the kernels of the last environment precompute (HIP library only): dict of ms."""
+        a = np.zeros(4, np.float32)
+        self._check(self.api.get_precompute_ms(self._ctx, B.fptr(a)), "get_precompute_ms")
+        return dict(zip(("to_cube", "irradiance", "prefilter", "brdf_lut"), (float(v) for v in a)))
+
     def read_brdf_lut(self):
         w, h = C.c_uint32(), C.c_uint32()
         self._check(self.api.read_brdf_lut(self._ctx, None, C.byref(w), C.byref(h)), "read_brdf_lut")

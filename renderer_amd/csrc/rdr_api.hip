@@ -266,6 +266,7 @@ struct rdr_ctx {
     struct AltBuffers { DevBuf batch_tables, frame, shade_tris, recs, keys[2], vals[2], tile_start, depth, vis, dir_shadow, hdr, ofrag_recs, pixel_state, tile_first; } alt[RDR_FRAME_SLOTS - 1];
     PinBuf h_frame;                 // staging of DFrame + lights, one half per frame slot (h_stage is busy with the batch tables at that point)
     unsigned char* noalloc_scratch = nullptr;  // address of `scratch` on this context's device
+    float precompute_ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // device time of the last conversion to cube faces, irradiance bake, prefilter bake, BRDF table
 };
 
 namespace {
@@ -1517,6 +1518,23 @@ int rdr_set_lights(rdr_ctx* c, const rdr_point_light* lights, uint32_t count, co
     return RDR_OK;
 }
 
+// Device time of a group of launches on the context's stream (the precompute calls synchronise anyway).
+struct StreamTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    explicit StreamTimer(hipStream_t s) : st(s) {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess || hipEventRecord(a, st) != hipSuccess) { release(); }
+    }
+    float stop() {  // waits for the launches; 0 if the events could not be made
+        float ms = 0.0f;
+        if (a && b && hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+        release();
+        return ms;
+    }
+    void release() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); a = b = nullptr; }
+    ~StreamTimer() { release(); }
+};
+
 // Both bakes from the packed cube in d_env (the second half of setEnvironmentMap).
 static int bake_environment(rdr_ctx* c, uint32_t w) {
     memset(&c->env, 0, sizeof c->env);
@@ -1531,7 +1549,9 @@ static int bake_environment(rdr_ctx* c, uint32_t w) {
         const float stepRads = 2 * PI / nSamples;
         for (int i = 0; i < 24; i++) { const float phi = i * stepRads; tb.cos_phi[i] = cosf(phi); tb.sin_phi[i] = sinf(phi); }
         for (int j = 0; j < 6; j++) { const float theta = j * stepRads; tb.sin_theta[j] = sinf(theta); tb.cos_theta[j] = cosf(theta); }
+        StreamTimer t(c->stream);
         launch_bake_irradiance(c->stream, c->env, c->d_irradiance.as<uint32_t>(), res, tb);
+        c->precompute_ms[1] = t.stop();
         memset(&c->irradiance, 0, sizeof c->irradiance);
         c->irradiance.texels = c->d_irradiance.as<uint32_t>(); c->irradiance.res = res; c->irradiance.levels = 1;
     }
@@ -1552,9 +1572,11 @@ static int bake_environment(rdr_ctx* c, uint32_t w) {
         HIP_TRY(c->d_trig.ensure(256 * 4));
         HIP_TRY(hipMemcpyAsync(c->d_trig.p, trig.data(), 256 * 4, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        StreamTimer t(c->stream);
         for (int l = 0; l < levels; l++)
             launch_bake_prefilter(c->stream, c->env, c->d_prefiltered.as<uint32_t>() + c->prefiltered.level_offset[l], base >> l, (float)l / 9,
                                   c->d_trig.as<float>());
+        c->precompute_ms[2] = t.stop();
         c->prefiltered.texels = c->d_prefiltered.as<uint32_t>(); c->prefiltered.res = base; c->prefiltered.levels = levels;
     }
     // bordered copies for the shading kernels
@@ -1605,7 +1627,11 @@ int rdr_set_environment_equirect(rdr_ctx* c, const float* pano, uint32_t w, uint
     DevBuf staging;
     HIP_TRY(staging.ensure((size_t)w * h * 16));
     HIP_TRY(hipMemcpyAsync(staging.p, pano, (size_t)w * h * 16, hipMemcpyHostToDevice, c->stream));
-    launch_equirect_to_cube(c->stream, staging.p, (int)w, (int)h, c->d_env.as<uint32_t>(), (int)face_res);
+    {
+        StreamTimer t(c->stream);
+        launch_equirect_to_cube(c->stream, staging.p, (int)w, (int)h, c->d_env.as<uint32_t>(), (int)face_res);
+        c->precompute_ms[0] = t.stop();
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     staging.release();
     return bake_environment(c, face_res);
@@ -1623,11 +1649,21 @@ int rdr_generate_brdf_lut(rdr_ctx* c, uint32_t size, uint32_t samples) {
     HIP_TRY(d_trig.ensure(trig.size() * 4));
     HIP_TRY(hipMemcpyAsync(d_trig.p, trig.data(), trig.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c->d_lut.ensure((size_t)size * size * 4 + 16));  // spare words: the shading kernels read texel pairs
-    launch_brdf_lut(c->stream, c->d_lut.as<uint32_t>(), (int)size, (int)samples, d_trig.as<float>());
+    {
+        StreamTimer t(c->stream);
+        launch_brdf_lut(c->stream, c->d_lut.as<uint32_t>(), (int)size, (int)samples, d_trig.as<float>());
+        c->precompute_ms[3] = t.stop();
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     d_trig.release();
     c->lut_w = c->lut_h = size;
+    return RDR_OK;
+}
+
+int rdr_get_precompute_ms(rdr_ctx* c, float out[4]) {
+    if (!c || !out) return RDR_ERR_INVALID;
+    memcpy(out, c->precompute_ms, sizeof c->precompute_ms);
     return RDR_OK;
 }
 
