@@ -271,6 +271,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--quads", type=int, default=2236, help="config 5: quads per side of the grid (2236 -> 10 M triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rest", action="store_true", help="skip the second measurement of the headline (props at rest): profiling runs")
     ap.add_argument("--cpu-frames", type=int, default=None)
     ap.add_argument("--diag-lights", type=int, default=-1, help="diagnostic only: keep the first N point lights (not the benchmark workload)")
     a = ap.parse_args()
@@ -364,7 +365,7 @@ def main():
         raise SystemExit(f"expected {a.gpus} ranks with {a.steps} timed frames each, saw {[(p[1]) for p in per_rank]}")
     # the same frames with the dynamic props standing still (headline configuration only): what the shadow-view reuse buys
     at_rest = None
-    if a.config == 2:
+    if a.config == 2 and not a.no_rest:
         rest_fn = lambda rr, st, k: frame_sponza(rr, st, k, props_move=False)  # noqa: E731
         sharder.run(3 * world, lambda rr, k: rest_fn(rr, info, k), frame_params)
         e2, acc2, _, extra2, _ = timed_run((a.warmup + a.steps) * world, a.steps, rest_fn)

@@ -229,6 +229,32 @@ RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float
     }
 }
 
+// `cube` is a footprint-major copy (k_cube_quads): the whole 2x2 footprint at (i0, j0) is one 16-byte entry.
+typedef uint32_t rdr_uint4_t __attribute__((ext_vector_type(4)));
+RDR_DEV void cube_sample_quad(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
+#pragma clang fp contract(fast)
+    float s, t;
+    const int face = cube_face_fast(dx, dy, dz, s, t);
+    const uint32_t rr = cube.res >> level;
+    const int r = (int)(rr ? rr : 1u), pitch = r + 1;
+    const RDR_GLOBAL rdr_uint4_t* px = (const RDR_GLOBAL rdr_uint4_t*)as_global(cube.texels) + cube.level_offset[level];
+    const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = min(max((int)fu, -1), r - 1), j0 = min(max((int)fv, -1), r - 1);
+    const rdr_uint4_t q = px[(face * pitch + j0 + 1) * pitch + i0 + 1];
+    float c00[3], c10[3], c01[3], c11[3];
+    unpack_r11g11b10(q.x, c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(q.y, c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(q.z, c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(q.w, c11[0], c11[1], c11[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float top = fmaf(a, c10[k] - c00[k], c00[k]), bot = fmaf(a, c11[k] - c01[k], c01[k]);
+        out[k] = fmaf(b, bot - top, top);
+    }
+}
+
 // ---- 2D material textures: trilinear, isotropic LOD
 #define RDR_INV255 (1.0f / 255.0f)
 

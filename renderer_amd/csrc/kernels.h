@@ -117,6 +117,10 @@ void launch_shadow_cube_border(hipStream_t s, float* maps, int res, uint32_t n_c
 void launch_fill_f32(hipStream_t s, float* dst, float v, size_t n);
 // one level of a cube (6 x res^2 words) -> the same level with a one-texel border per face (6 x (res + 2)^2 words)
 void launch_cube_border(hipStream_t s, const uint32_t* src, uint32_t* dst, int res);
+// footprint-major copies for the shading kernels: one bordered cube level -> 6 x (res + 1)^2 entries of four texels;
+// the w x h BRDF table -> w x h entries of four texels (REPEAT)
+void launch_cube_quads(hipStream_t s, const uint32_t* bordered, void* dst, int res);
+void launch_lut_quads(hipStream_t s, const uint32_t* src, void* dst, int w, int h);
 void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb);
 void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig);
 void launch_mip_blit(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int srgb, const float* srgb_decode,

@@ -255,6 +255,30 @@ __global__ void __launch_bounds__(256) k_cube_border(const uint32_t* __restrict_
     dst[t] = src[cube_texel_offset(face, rem % p - 1, rem / p - 1, res)];
 }
 
+// Footprint-major copy of one bordered cube level: entry ((face * (res + 1) + j0 + 1) * (res + 1) + i0 + 1) holds the
+// four texels (i0, j0), (i0 + 1, j0), (i0, j0 + 1), (i0 + 1, j0 + 1) of the 2x2 filter footprint whose top-left texel is
+// (i0, j0), i0 and j0 in [-1, res - 1]. The fragments of a wave look the image-based term up in directions that the
+// normal maps scatter: with one 16-byte entry per look-up every lane touches one cache line where two rows of a
+// row-major image cost it two (same texels, same arithmetic, four times the memory: 34 MB for the prefiltered cube).
+__global__ void __launch_bounds__(256) k_cube_quads(const uint32_t* __restrict__ bordered, uint4* __restrict__ dst, int res) {
+    const int p = res + 2, q = res + 1;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= 6u * (uint32_t)(q * q)) return;
+    const int face = (int)(t / (uint32_t)(q * q)), rem = (int)(t % (uint32_t)(q * q));
+    const int I = rem % q, J = rem / q;  // = i0 + 1, j0 + 1: position of the footprint's first texel in the bordered face
+    const uint32_t* row = bordered + ((size_t)face * p + J) * p + I;
+    dst[t] = make_uint4(row[0], row[1], row[p], row[p + 1]);
+}
+// The same for the split-sum table, which is addressed with REPEAT: entry (i, j) holds texels (i, j), (i + 1, j),
+// (i, j + 1), (i + 1, j + 1) with the indices wrapped.
+__global__ void __launch_bounds__(256) k_lut_quads(const uint32_t* __restrict__ src, uint4* __restrict__ dst, int w, int h) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= (uint32_t)(w * h)) return;
+    const int i = (int)(t % (uint32_t)w), j = (int)(t / (uint32_t)w);
+    const int i1 = i + 1 == w ? 0 : i + 1, j1 = j + 1 == h ? 0 : j + 1;
+    dst[t] = make_uint4(src[j * w + i], src[j * w + i1], src[j1 * w + i], src[j1 * w + i1]);
+}
+
 // Border of the point-light shadow cubes, in place: face `f` of cube `c` is a (res + 2)^2 image whose interior the
 // rasteriser writes; its one-texel border receives the depth across the shared cube edges (cube_fold), so that the
 // 2x2 compare footprint of a shadow look-up is four neighbouring words anywhere on the face. One thread per
@@ -299,6 +323,13 @@ void launch_fill_f32(hipStream_t s, float* dst, float v, size_t n) {
 void launch_cube_border(hipStream_t s, const uint32_t* src, uint32_t* dst, int res) {
     const uint32_t n = 6u * (uint32_t)(res + 2) * (uint32_t)(res + 2);
     hipLaunchKernelGGL(k_cube_border, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, res);
+}
+void launch_cube_quads(hipStream_t s, const uint32_t* bordered, void* dst, int res) {
+    const uint32_t n = 6u * (uint32_t)(res + 1) * (uint32_t)(res + 1);
+    hipLaunchKernelGGL(k_cube_quads, dim3((n + 255) / 256), dim3(256), 0, s, bordered, (uint4*)dst, res);
+}
+void launch_lut_quads(hipStream_t s, const uint32_t* src, void* dst, int w, int h) {
+    hipLaunchKernelGGL(k_lut_quads, dim3(((uint32_t)(w * h) + 255) / 256), dim3(256), 0, s, src, (uint4*)dst, w, h);
 }
 void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb) {
     hipLaunchKernelGGL(k_bake_irradiance, dim3((6u * res * res + 255) / 256), dim3(256), 0, s, env, dst, res, tb);

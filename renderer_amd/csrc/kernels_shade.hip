@@ -411,21 +411,17 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const float fl = floorf(lod), ff = lod - fl;
         const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, fr.prefiltered.levels - 1u);
         float s0[3], s1[3], irr[3], lut[2];
-        cube_sample_fast(fr.prefiltered, l0, Rv.x, Rv.y, Rv.z, s0);
-        cube_sample_fast(fr.prefiltered, l1, Rv.x, Rv.y, Rv.z, s1);
+        cube_sample_quad(fr.prefiltered, l0, Rv.x, Rv.y, Rv.z, s0);
+        cube_sample_quad(fr.prefiltered, l1, Rv.x, Rv.y, Rv.z, s1);
         {
             const int w = (int)fr.lut_w, h = (int)fr.lut_h;
             int i0, i1, j0, j1;
             float a, b;
             tex_axis(NdotV, w, 0u, i0, i1, a);
             tex_axis(roughness, h, 0u, j0, j1, b);
-            const RDR_GLOBAL uint32_t* lp = as_global((const uint32_t*)fr.lut);
-            // the two texels of a row are neighbours unless the footprint wraps around the edge (the table's buffer ends in
-            // spare words, so the pair at the last texel stays inside it)
-            uint32_t q00, q10, q01, q11;
-            load_pair(lp + (j0 * w + i0), q00, q10);
-            load_pair(lp + (j1 * w + i0), q01, q11);
-            if (i1 != i0 + 1) { q10 = lp[j0 * w + i1]; q11 = lp[j1 * w + i1]; }
+            // footprint-major table: the four texels of the (wrapped) footprint at (i0, j0) are one 16-byte entry
+            const rdr_uint4_t q = ((const RDR_GLOBAL rdr_uint4_t*)as_global((const uint32_t*)fr.lut))[j0 * w + i0];
+            const uint32_t q00 = q.x, q10 = q.y, q01 = q.z, q11 = q.w;
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const float t00 = (float)((q00 >> (8 * k)) & 255u) * RDR_INV255, t10 = (float)((q10 >> (8 * k)) & 255u) * RDR_INV255;
@@ -434,7 +430,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
                 lut[k] = (1.0f - b) * top + b * bot;
             }
         }
-        cube_sample_fast(fr.irradiance, 0, N.x, N.y, N.z, irr);
+        cube_sample_quad(fr.irradiance, 0, N.x, N.y, N.z, irr);
         const float x = 1.0f - clampf(NdotV, 0.0f, 1.0f);
         const float x2 = x * x, x5 = x2 * x2 * x;
         const float F[3] = {F0.x + (1.0f - F0.x) * x5, F0.y + (1.0f - F0.y) * x5, F0.z + (1.0f - F0.z) * x5};

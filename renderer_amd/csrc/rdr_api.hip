@@ -171,6 +171,10 @@ struct rdr_ctx {
     // the three cubes again with a one-texel border per face (k_cube_border): what the shading kernels filter from
     DevBuf d_env_b, d_irradiance_b, d_prefiltered_b;
     DCube env_b{}, irradiance_b{}, prefiltered_b{};
+    // ... and footprint-major copies of the two the fragments look up in scattered directions, and of the BRDF table
+    // (k_cube_quads, k_lut_quads): one 16-byte entry per 2x2 footprint
+    DevBuf d_irradiance_q, d_prefiltered_q, d_lut_q;
+    DCube irradiance_q{}, prefiltered_q{};
     uint32_t lut_w = 0, lut_h = 0;
 
     // frame targets
@@ -1222,7 +1226,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
                       &c->d_counters, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1],
-                      &c->d_prim_cull, &c->d_models, &c->d_cand, &c->d_draw_scratch};
+                      &c->d_prim_cull, &c->d_models, &c->d_cand, &c->d_draw_scratch, &c->d_irradiance_q, &c->d_prefiltered_q, &c->d_lut_q};
     for (DevBuf* b : bufs) b->release();
     for (rdr_ctx::AltBuffers& a : c->alt) {
         DevBuf* alts[] = {&a.batch_tables, &a.frame, &a.shade_tris, &a.recs, &a.keys[0], &a.keys[1], &a.vals[0], &a.vals[1], &a.tile_start, &a.depth, &a.vis,
@@ -1597,6 +1601,23 @@ static int bake_environment(rdr_ctx* c, uint32_t w) {
     RDR_TRY(add_border(c->env, c->d_env_b, c->env_b));
     RDR_TRY(add_border(c->irradiance, c->d_irradiance_b, c->irradiance_b));
     RDR_TRY(add_border(c->prefiltered, c->d_prefiltered_b, c->prefiltered_b));
+    auto add_quads = [&](const DCube& bordered, DevBuf& buf, DCube& dst) -> int {
+        dst = bordered;
+        size_t off = 0;
+        for (uint32_t l = 0; l < bordered.levels; l++) {
+            const size_t r = std::max(1u, bordered.res >> l);
+            dst.level_offset[l] = (uint32_t)off;
+            off += 6 * (r + 1) * (r + 1);
+        }
+        HIP_TRY(buf.ensure(off * 16));
+        for (uint32_t l = 0; l < bordered.levels; l++)
+            launch_cube_quads(c->stream, bordered.texels + bordered.level_offset[l], buf.as<uint8_t>() + (size_t)dst.level_offset[l] * 16,
+                              (int)std::max(1u, bordered.res >> l));
+        dst.texels = buf.as<uint32_t>();
+        return RDR_OK;
+    };
+    RDR_TRY(add_quads(c->irradiance_b, c->d_irradiance_q, c->irradiance_q));
+    RDR_TRY(add_quads(c->prefiltered_b, c->d_prefiltered_q, c->prefiltered_q));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     return RDR_OK;
@@ -1637,6 +1658,15 @@ int rdr_set_environment_equirect(rdr_ctx* c, const float* pano, uint32_t w, uint
     return bake_environment(c, face_res);
 }
 
+// footprint-major copy of the BRDF table in d_lut (what the shading kernels read)
+static int make_lut_quads(rdr_ctx* c) {
+    HIP_TRY(c->d_lut_q.ensure((size_t)c->lut_w * c->lut_h * 16));
+    launch_lut_quads(c->stream, c->d_lut.as<uint32_t>(), c->d_lut_q.p, (int)c->lut_w, (int)c->lut_h);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return RDR_OK;
+}
+
 int rdr_generate_brdf_lut(rdr_ctx* c, uint32_t size, uint32_t samples) {
     if (!c || size == 0 || size > 4096 || samples == 0 || samples > 65536) return fail(c, RDR_ERR_INVALID, "generate_brdf_lut: bad argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -1658,7 +1688,7 @@ int rdr_generate_brdf_lut(rdr_ctx* c, uint32_t size, uint32_t samples) {
     HIP_TRY(hipGetLastError());
     d_trig.release();
     c->lut_w = c->lut_h = size;
-    return RDR_OK;
+    return make_lut_quads(c);
 }
 
 int rdr_get_precompute_ms(rdr_ctx* c, float out[4]) {
@@ -1690,7 +1720,7 @@ int rdr_set_brdf_lut(rdr_ctx* c, const uint8_t* px, uint32_t w, uint32_t h, uint
     HIP_TRY(c->d_lut.ensure(rgba.size() + 16));  // spare words: the shading kernels read texel pairs
     HIP_TRY(hipMemcpy(c->d_lut.p, rgba.data(), rgba.size(), hipMemcpyHostToDevice));
     c->lut_w = w; c->lut_h = h;
-    return RDR_OK;
+    return make_lut_quads(c);
 }
 
 int rdr_set_camera(rdr_ctx* c, const rdr_camera* cam) {
@@ -1833,8 +1863,8 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         HIP_TRY(c->d_frame.ensure(off_l + sz_l));
         c->d_lights.p = c->d_frame.as<uint8_t>() + off_l;
         fr.lights = c->d_lights.as<DPointLight>();
-        fr.env = c->env_b; fr.irradiance = c->irradiance_b; fr.prefiltered = c->prefiltered_b;  // bordered copies
-        fr.lut = c->d_lut.as<uint8_t>(); fr.lut_w = c->lut_w; fr.lut_h = c->lut_h;
+        fr.env = c->env_b; fr.irradiance = c->irradiance_q; fr.prefiltered = c->prefiltered_q;  // bordered / footprint-major copies
+        fr.lut = c->d_lut_q.as<uint8_t>(); fr.lut_w = c->lut_w; fr.lut_h = c->lut_h;
         fr.textures = c->d_textures.as<DTexture>(); fr.prims = c->d_prims.as<DPrim>();
         fr.pos = c->d_pos.as<float4>(); fr.attr = c->d_attr.as<DVertexAttr>(); fr.idx = c->d_idx.as<uint32_t>();
         fr.srgb_decode = c->d_tables.as<float>(); fr.unorm_decode = c->d_tables.as<float>() + 256;

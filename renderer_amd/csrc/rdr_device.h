@@ -175,8 +175,9 @@ struct DFrame {
     const float* dir_shadow;    // [cascade][res + 4][res + 4]: two texels of border holding 1.0 (clamp-to-border, white)
     const float* point_shadow;  // [slot*6+face][res + 2][res + 2]: one texel of border holding the texels across the cube edges
     const DPointLight* lights;
-    DCube env, irradiance, prefiltered;
-    const uint8_t* lut;  // RGBA8
+    DCube env;                      // bordered faces, (res + 2)^2 words each (the sky's look-ups are coherent)
+    DCube irradiance, prefiltered;  // footprint-major: `texels` points at 16-byte entries of four texels, level_offset counts entries
+    const uint8_t* lut;             // footprint-major RGBA8 table: lut_w x lut_h entries of four texels
     uint32_t lut_w, lut_h;
     const DTexture* textures;
     const DPrim* prims;

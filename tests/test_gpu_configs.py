@@ -37,6 +37,22 @@ def test_config1_helmet_like_reduced(orc_capi, hip_capi):
             assert np.array_equal(ro.read_env_cube(which, level), rh.read_env_cube(which, level)), (which, level)
 
 
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_config1_helmet_like_at_its_stated_size(orc_capi, hip_capi, msaa):
+    """Config 1 as BASELINE.json states it: 1920x1080, the ~69k-triangle object with five 2048^2 textures, directional
+    light with the default 4 x 2048^2 cascades, IBL, bloom + tonemap, at 1 and 4 samples per pixel, from two
+    cameras (the second close enough for the textures to be magnified over part of the object)."""
+    ro, rh = hp.make_pair(orc_capi, hip_capi, 1920, 1080, msaa=msaa)
+    for r in (ro, rh):
+        scenes.helmet_like(r, tex_size=2048)
+    compare_frame(ro, rh)
+    vis = rh.read_visibility()
+    assert 0.15 < (vis[0] != 0xFFFFFFFF).mean() < 0.9, "the object covers part of the frame"
+    for r in (ro, rh):
+        r.set_camera(position=(0.9, 0.5, 1.5), euler=(-0.25, 0.55, 0.0))
+    compare_frame(ro, rh)
+
+
 def test_config2_sponza_like_reduced(orc_capi, hip_capi):
     """Config 2: the hall with 16 point lights (8 shadowed), MASK and BLEND prims, at quarter detail and 640x360."""
     kw = dict(msaa=4, directional_shadow_map_resolution=1024, point_shadow_map_resolution=256)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for path in renderer_amd/lib/librdr_hip*.so; do
   lib=$(basename $path .so)
-  RDR_HIP_LIB=$PWD/$path timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt_$lib -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/kt_$lib.log 2>&1
+  RDR_HIP_LIB=$PWD/$path timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt_$lib -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-rest > gpurun_out/kt_$lib.log 2>&1
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/kt_$lib/**/*kernel_trace.csv", recursive=True)[0]

@@ -3,7 +3,7 @@
 # whose names start with PREFIX.   tools/pmc_kernel.sh TAG PREFIX COUNTER...   (at most 8 SQ counters per pass)
 TAG=$1; PREFIX=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pk_$TAG -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/pk_$TAG.log 2>&1 || { tail -5 gpurun_out/pk_$TAG.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pk_$TAG -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-rest > gpurun_out/pk_$TAG.log 2>&1 || { tail -5 gpurun_out/pk_$TAG.log; exit 1; }
 python3 - "$TAG" "$PREFIX" <<'PY'
 import csv, glob, collections, sys
 tag, prefix = sys.argv[1], sys.argv[2]
