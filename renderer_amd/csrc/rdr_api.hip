@@ -256,6 +256,7 @@ struct rdr_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_raster1 = nullptr;  // the rasteriser launches of `stream` of the last batch are done
+    hipEvent_t ev_vertex_in = nullptr, ev_vertex_out = nullptr;  // the main view's vertex stage (k_shade_setup on stream3): its inputs are there / it is done
     bool raster_side = false;         // ... and its 4x rasteriser ran on stream3 (ev_join)
     hipStream_t raster_stream = nullptr;  // stream the shadow-view rasteriser of the last batch was enqueued on
     // Geometry and shading of consecutive frames overlap: `stream` carries the geometry phase of a frame (set-up, binning,
@@ -1174,6 +1175,8 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_raster1, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_vertex_in, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_vertex_out, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreate(&c->stream3) == hipSuccess && hipStreamCreate(&c->stream4) == hipSuccess;
     for (int i = 0; i < RDR_FRAME_SLOTS && ok; i++) ok = hipEventCreateWithFlags(&c->ev_shaded[i], hipEventDisableTiming) == hipSuccess;
     // decode tables: [0..255] sRGB EOTF, [256..511] i/255, [512..767] sRGB encode thresholds
@@ -1240,6 +1243,8 @@ void rdr_destroy(rdr_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_raster1) (void)hipEventDestroy(c->ev_raster1);
+    if (c->ev_vertex_in) (void)hipEventDestroy(c->ev_vertex_in);
+    if (c->ev_vertex_out) (void)hipEventDestroy(c->ev_vertex_out);
     for (int i = 0; i < RDR_FRAME_SLOTS; i++) if (c->ev_shaded[i]) (void)hipEventDestroy(c->ev_shaded[i]);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
@@ -1787,6 +1792,8 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         const char* e = getenv("RDR_DEVICE_DRAW_LISTS");
         c->device_draws = e ? atoi(e) != 0 : c->prims.size() >= 2048;
     }
+    // the pair counts exist once: the previous frame's vertex stage (stream3) reads them until it is done
+    if (c->frames > 1) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vertex_out, 0));
     HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_SLOT_BYTES, c->stream));
     if (c->device_draws) RDR_TRY(upload_cull_tables(c));  // the candidate lists the views below refer to
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -1882,14 +1889,24 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         HIP_TRY(c->d_shade_tris.ensure(std::max<size_t>((size_t)n_main_tris + n_blend_tris, 1) * sizeof(DShadeTri)));
         tris_main = c->d_shade_tris.as<DShadeTri>();
         tris_blend = tris_main + n_main_tris;
-        launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_main_draw, c->d_first_tri.as<uint32_t>() + first_main_draw,
+        // The vertex stage needs the pair scan and the frame constants, and only the shading needs the vertex stage: it
+        // goes to the stream the 4x rasteriser will take later (idle until the sort is done), beside the pair expansion
+        // and the sort instead of in front of them (RDR_VERTEX_STAGE_IN_LINE=1: on the front-end stream, a measurement aid).
+        const char* in_line = getenv("RDR_VERTEX_STAGE_IN_LINE");
+        hipStream_t vs = (in_line && atoi(in_line)) ? c->stream : c->stream3;
+        if (vs != c->stream) {
+            HIP_TRY(hipEventRecord(c->ev_vertex_in, c->stream));
+            HIP_TRY(hipStreamWaitEvent(vs, c->ev_vertex_in, 0));
+        }
+        launch_shade_setup(vs, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_main_draw, c->d_first_tri.as<uint32_t>() + first_main_draw,
                            (uint32_t)n_main_draws, n_main_tris, c->d_pair_count.as<uint32_t>() + main_first_instance,
                            c->batch_instances - main_first_instance, frame_counters(c), tris_main);
         if (have_blend)
-            launch_shade_setup(c->stream, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_blend_draw,
+            launch_shade_setup(vs, c->d_frame.as<DFrame>(), c->d_draws.as<DDraw>() + first_blend_draw,
                                c->d_first_tri.as<uint32_t>() + first_blend_draw, (uint32_t)n_blend_draws, n_blend_tris,
                                c->d_pair_count.as<uint32_t>() + blend_first_instance, c->batch_instances - blend_first_instance,
                                frame_counters(c), tris_blend);
+        HIP_TRY(hipEventRecord(c->ev_vertex_out, vs));
         return RDR_OK;
     };
     const size_t frag_slots = shade_frag_slots(W, H, (int)S);
@@ -1914,6 +1931,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     // behind the previous frame's shading and tail
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_raster1, 0));
     if (c->raster_side) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_join, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_vertex_out, 0));
     // What follows the shading kernel (resolve, blended pass) goes to the tail stream in front of the post chain: the
     // shading stream then holds only shadow-view rasterisers and shading kernels, and the next frame's rasteriser does
     // not queue behind this frame's blended pass. The fragment colours exist once, so the shading kernel waits for
