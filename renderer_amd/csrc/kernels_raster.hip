@@ -510,14 +510,31 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
 // A point-light face that moving meshes are drawn on top of starts from its cached static map (DView::init, load == 1
 // with init != depth). The map is copied to the target in one bandwidth-bound sweep before the face is rasterised, so
 // the tiles without triangles - nearly all of such a face - cost the rasteriser one load of their list bounds.
-// grid: (ceil(max w / 256), max h, views); `views` is the batch's table in device memory (a view the draw-list kernels
-// dropped, load == 3, is left alone).
+// Such a target is a bordered face (pitch = w + 2, one texel around the h rows, both maps laid out alike): the sweep
+// takes the whole padded face, rows and border in one run of 16-byte words where the face's size and place allow it
+// (the border is written again from the neighbouring faces once the rasteriser is through, k_shadow_cube_border).
+// grid: (blocks over the padded face, 1, views); `views` is the batch's table in device memory (a view the draw-list
+// kernels dropped, load == 3, is left alone).
 __global__ void __launch_bounds__(256) k_view_init(const DView* __restrict__ views, uint32_t first_view) {
     const DView& vw = views[first_view + blockIdx.z];
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
-    if (vw.samples != 1u || vw.load != 1u || vw.init == vw.depth || x >= vw.w || y >= vw.h) return;
-    const size_t at = (size_t)y * vw.pitch + x;
-    vw.depth[at] = vw.init[at];
+    if (vw.samples != 1u || vw.load != 1u || vw.init == vw.depth) return;
+    if (vw.pitch != vw.w + 2u) {  // not a bordered face: the rows alone
+        const size_t i0 = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+        for (size_t k = i0; k < min((size_t)vw.w * vw.h, i0 + 4u); k++) {
+            const size_t at = k / vw.w * vw.pitch + k % vw.w;
+            vw.depth[at] = vw.init[at];
+        }
+        return;
+    }
+    const size_t lead = (size_t)vw.pitch + 1u, n = (size_t)vw.pitch * (vw.h + 2u);
+    float* dst = vw.depth - lead;
+    const float* src = vw.init - lead;
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0u && (n & 3u) == 0u) {
+        if (i * 4u < n) ((rdr_uint4_t*)dst)[i] = ((const rdr_uint4_t*)src)[i];
+    } else {
+        for (size_t k = i * 4u; k < min(n, i * 4u + 4u); k++) dst[k] = src[k];
+    }
 }
 
 // CLASSIFY (the 4x view of a frame): the tile's samples are also turned into the fragment lists the opaque shading works
@@ -877,10 +894,10 @@ void launch_raster(hipStream_t s, const DView* views, uint32_t n_views, const DV
     uint32_t last = r.first_view;
     while (last + 1 < n_views && views[last + 1].tile_base < r.end_tile) last++;
     if (samples == 1) {
-        uint32_t mw = 0, mh = 0;
+        size_t texels = 0;
         for (uint32_t v = r.first_view; v <= last; v++)
-            if (views[v].load == 1u && views[v].init != views[v].depth) { mw = max(mw, views[v].w); mh = max(mh, views[v].h); }
-        if (mw) hipLaunchKernelGGL(k_view_init, dim3((mw + 255u) / 256u, mh, last - r.first_view + 1u), dim3(256), 0, s, d_views, r.first_view);
+            if (views[v].load == 1u && views[v].init != views[v].depth) texels = max(texels, (size_t)views[v].pitch * (views[v].h + 2u));
+        if (texels) hipLaunchKernelGGL(k_view_init, dim3((uint32_t)((texels + 1023u) / 1024u), 1, last - r.first_view + 1u), dim3(256), 0, s, d_views, r.first_view);
     }
     for (uint32_t v0 = r.first_view; v0 <= last; v0 += RDR_RASTER_MAX_VIEWS) {
         RasterViews tbl;

@@ -294,6 +294,9 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
     __builtin_amdgcn_sched_barrier(0);  // the loads below stay below: the record is consumed in stages, not held whole
     const DShadeTri& mt = M;  // material block and texture descriptors travel with the triangle
 
+#ifndef RDR_SHADOW_ALWAYS
+#define RDR_SHADOW_ALWAYS 0  // measurement aid: point-light shadow look-ups even where no fragment of the wave needs them
+#endif
 #ifndef RDR_DIAG
 #define RDR_DIAG 0  // diagnostic builds only: bit 0 no textures, bit 1 no directional light, bit 2 no IBL, bit 3 nothing after interpolation, bit 4 no point lights, bit 5 no point-light shadow lookups
 #endif
@@ -464,25 +467,28 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const v2f d2 = __builtin_elementwise_fma(Lz, Lz, __builtin_elementwise_fma(Ly, Ly, Lx * Lx));  // distance^2
         const v2f nl = __builtin_elementwise_fma(v2s(N.z), Lz, __builtin_elementwise_fma(v2s(N.y), Ly, N.x * Lx));
         const v2f vl = __builtin_elementwise_fma(v2s(V.z), Lz, __builtin_elementwise_fma(v2s(V.y), Ly, V.x * Lx));
+        // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
+        const bool lit[2] = {!(fmaxf(pl.ix[0], fmaxf(pl.iy[0], pl.iz[0])) <= 1e-3f * d2.x), !(fmaxf(pl.ix[1], fmaxf(pl.iy[1], pl.iz[1])) <= 1e-3f * d2.y)};
         float sh[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says.
-            // No per-lane branch here: the look-ups of the pair then sit in one block of code and their loads are in
-            // flight together; a lane that does not need the result computes it on a valid address and drops it.
+            // A light behind the shaded surface contributes radiance * max(N.L, 0) = 0 whatever its shadow test says, and
+            // one too far away is skipped. The look-up is left out only when no fragment of the wave needs it (a uniform
+            // branch; neighbouring fragments mostly face the same way): within a wave there is no per-lane branch, so
+            // that the look-ups of the pair sit in one block of code and their loads are in flight together; a lane
+            // that does not need the result computes it on a valid address and drops it.
+            const bool need = nl[j] > 0.0f && lit[j];
             float shadowTest = 1.0f;
-            if ((pl.flags[j] & 3u) == 3u && !(RDR_DIAG & 32)) {  // uniform: casts shadows and has a map
+            if ((pl.flags[j] & 3u) == 3u && !(RDR_DIAG & 32) && (RDR_SHADOW_ALWAYS || __any(need))) {  // uniform: casts shadows, has a map, is needed
                 const float lx = Lx[j], ly = Ly[j], lz = Lz[j];
                 const float lightDepth = fmaxf(fabsf(lx), fmaxf(fabsf(ly), fabsf(lz))) - 0.05f;
                 const float ref = c0 - c1 / lightDepth;  // IEEE divide: this value is compared with stored depths
-                shadowTest = shadow_cube(fr, pl.slot[j], -lx, -ly, -lz, ref, nl[j] > 0.0f);
+                shadowTest = shadow_cube(fr, pl.slot[j], -lx, -ly, -lz, ref, need);
                 shadowTest = shadowTest < 1e-3f ? 0.0f : shadowTest;  // pbr.frag:151
             }
-            sh[j] = nl[j] > 0.0f ? shadowTest : 0.0f;
+            sh[j] = need ? shadowTest : 0.0f;
         }
-        // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
-        const bool on0 = !(fmaxf(pl.ix[0], fmaxf(pl.iy[0], pl.iz[0])) <= 1e-3f * d2.x) && sh[0] != 0.0f;
-        const bool on1 = !(fmaxf(pl.ix[1], fmaxf(pl.iy[1], pl.iz[1])) <= 1e-3f * d2.y) && sh[1] != 0.0f;
+        const bool on0 = sh[0] != 0.0f, on1 = sh[1] != 0.0f;
         if (!__any(on0 || on1)) continue;  // uniform
         // a light with a shadow map uses the normalised direction, one without does not (pbr.frag:154-158)
         const bool unit0 = (pl.flags[0] & 3u) == 3u, unit1 = (pl.flags[1] & 3u) == 3u;

@@ -236,6 +236,11 @@ struct rdr_ctx {
     uint32_t point_cubes_in_use = 0;
     unsigned long long frame_pairs_before = 0;  // (triangle, tile) pairs of the batches of this frame binned so far
     double host_wait_s = 0.0;           // time the current rdr_render_frame call has spent blocked on the GPU
+    // RDR_TRACE_FRAME=1: where a frame's time goes, printed to stderr when the frame is picked up. Device times (events
+    // behind set-up and behind the front end, beside the pass events) and the host's clock at the same points of the call.
+    bool trace = false;
+    hipEvent_t tr_ev[RDR_FRAME_SLOTS][2] = {};
+    double tr_host[RDR_FRAME_SLOTS][6] = {};
     float temporal_luminance = 0.0f, last_avg_log_lum = 0.0f;
     // Two frames are in flight, three on request: a frame rendered into a device destination is only enqueued, and the
     // next call (the next two, with `lag` = 2) builds and enqueues its own while the GPU still works on this one. Each
@@ -627,6 +632,18 @@ void harvest(rdr_ctx* c, int slot) {
     // ev[7] bracket the shading kernel on its own stream
     if (hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) st.ms_shade_kernel = ms;
     if (hipEventElapsedTime(&ms, ev[8], ev[1]) == hipSuccess) st.ms_raster_kernel = ms;
+    if (c->trace) {
+        auto at = [&](hipEvent_t e) { float t = -1.0f; return hipEventElapsedTime(&t, ev[0], e) == hipSuccess ? t * 1e3f : -1.0f; };
+        const int before = (slot + RDR_FRAME_SLOTS - 1) % RDR_FRAME_SLOTS;
+        float since = -1.0f;
+        if (hipEventElapsedTime(&since, c->ev_sets[before][0], ev[0]) != hipSuccess) since = -1.0f;
+        const double* h = c->tr_host[slot];
+        fprintf(stderr, "[rdr trace] frame start +%.0f us after the one before | device: set-up %.0f front end %.0f raster %.0f..%.0f shading %.0f..%.0f "
+                        "post %.0f end %.0f | host: pair wait %.0f..%.0f front end enqueued %.0f all enqueued %.0f return %.0f\n",
+                since * 1e3f, at(c->tr_ev[slot][0]), at(c->tr_ev[slot][1]), at(ev[8]), at(ev[1]), at(ev[6]), at(ev[7]), at(ev[2]), at(ev[5]),
+                (h[1] - h[0]) * 1e6, (h[2] - h[0]) * 1e6, (h[3] - h[0]) * 1e6, (h[4] - h[0]) * 1e6, (h[5] - h[0]) * 1e6);
+        (void)hipGetLastError();  // an event of the first frames that was never recorded
+    }
     c->done_stats = st;
     c->pending[slot].on = false;
 }
@@ -748,19 +765,22 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     launch_setup(c->stream, c->d_views.as<DView>(), c->d_draws.as<DDraw>(), c->d_draw_first.as<uint32_t>(), n_draws, n_inst,
                  c->d_prims.as<DPrim>(), c->d_pos.p, c->d_idx.as<uint32_t>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(),
                  counters + 16, c->d_chunk_first.as<uint32_t>(), n_chunks, c->d_chunk_bb.p, c->d_chunk_flags.as<uint8_t>());
-    launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
     HIP_TRY(c->h_read.ensure(RDR_READ_BYTES));
-    // scalar counters and spread counters in one copy; it lands beside the block the end of the frame is read into
+    // The host sizes the pair buffers from the sums set-up leaves in the spread counters, so the copy goes out in front
+    // of the scan: the scan runs while the count travels to the host and the host gets the next launches ready.
+    // (It lands beside the block the end of the frame is read into.)
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + RDR_READ_MID, counters, RDR_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_pairs, c->stream));
+    if (c->trace) (void)hipEventRecord(c->tr_ev[c->slot][0], c->stream);
+    launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
     if (after_scan) RDR_TRY(after_scan());
     {
         const double t_wait = host_now();
         HIP_TRY(hipEventSynchronize(c->ev_pairs));
         c->host_wait_s += host_now() - t_wait;
+        c->tr_host[c->slot][1] = t_wait; c->tr_host[c->slot][2] = host_now();
     }
     const uint32_t* mid = (const uint32_t*)(c->h_read.as<uint8_t>() + RDR_READ_MID);
-    const uint32_t n_pairs = mid[0];
     // what set-up summed over the triangles of the blended view (none in other batches): bounds for its fragment list
     c->blend_pairs = 0; c->blend_box_pixels = 0;
     unsigned long long pairs64 = 0;
@@ -772,11 +792,12 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
         memcpy(&a, slot + 6, 8);
         pairs64 += a;
     }
-    // the 32-bit scan total is only valid when the 64-bit sum set-up kept beside it fits (the counters run on over the
-    // batches of a frame: this batch's share is what was added since the batch before)
+    // pair positions are 32-bit (the counters run on over the batches of a frame: this batch's share is what was added
+    // since the batch before)
     const unsigned long long batch_pairs = pairs64 - c->frame_pairs_before;
     c->frame_pairs_before = pairs64;
-    if (batch_pairs >= 0xFFFFFFF0ull || batch_pairs != (unsigned long long)n_pairs)
+    const uint32_t n_pairs = (uint32_t)batch_pairs;
+    if (batch_pairs >= 0xFFFFFFF0ull)
         return fail(c, RDR_ERR_CAPACITY, "more than 2^32 (triangle, tile) pairs in one batch: too many large triangles over too many views");
     for (int k = 0; k < 2; k++) {
         HIP_TRY(c->d_keys[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
@@ -792,6 +813,7 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     uint32_t* vals[2] = {c->d_vals[0].as<uint32_t>(), c->d_vals[1].as<uint32_t>()};
     const int cur = launch_radix_sort(c->stream, keys, vals, n_pairs, key_bits, c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(), counters + 2);
     launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), n_tiles);
+    if (c->trace) { (void)hipEventRecord(c->tr_ev[c->slot][1], c->stream); c->tr_host[c->slot][3] = host_now(); }
     c->stats.triangle_instances += n_inst;
     c->stats.tile_pairs += n_pairs;
     c->stats.views += (uint32_t)b.views.size() - b.views_dropped;
@@ -803,6 +825,9 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
 // `after_scan`, if given, runs once set-up and the pair scan are enqueued and before the host waits for the pair
 // count: work enqueued there keeps the GPU busy while the host sizes the pair buffers.
 // `classify`: fragment lists the 4x rasteriser fills for the opaque pass (the frame's main batch), or null.
+// measurement switches: set and not 0
+bool env_on(const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; }
+
 int prev_slot(const rdr_ctx* c) { return (c->slot + RDR_FRAME_SLOTS - 1) % RDR_FRAME_SLOTS; }
 
 // `main_batch`: the frame's own batch. Its shadow-view rasteriser goes to the shading stream (in front of the frame's
@@ -868,6 +893,7 @@ int raster_batch(rdr_ctx* c, Batch& b, int* out_cur = nullptr, const std::functi
     launch(rs, rr[0], none);
     if (rr[1].first_tile < rr[1].end_tile) {
         // the point-light shadow maps exist once: the previous frame's shading may still be reading them
+        // (the faces with moving meshes in one launch with the views that start from a clear: 1 % fewer frames/s)
         if (c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(rs, c->ev_shaded[prev_slot(c)], 0));
         launch(rs, rr[1], none);
     }
@@ -1196,6 +1222,10 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     // 2 or 3 frames in flight (2 by default: a frame's results are there one call later; 3 gave +1 % frames/s on the
     // benchmark frame and a shading kernel 2 % longer for what runs beside it)
     if (getenv("RDR_TAIL_ON_SHADING_STREAM")) c->tail_split = false;
+    if (env_on("RDR_TRACE_FRAME")) {
+        c->trace = true;
+        for (int i = 0; i < RDR_FRAME_SLOTS * 2; i++) c->trace = c->trace && hipEventCreate(&c->tr_ev[i / 2][i % 2]) == hipSuccess;
+    }
     if (const char* e = getenv("RDR_FRAMES_IN_FLIGHT")) { const int v = atoi(e); if (v == 2 || v == 3) c->lag = v - 1; }
     // measurement aid: size of the fragment shading kernel's grid (a multiple of 8, one share per die)
     if (const char* e = getenv("RDR_SHADE_BLOCKS")) { const long v = atol(e); if (v >= 8 && v <= 65536) c->shade_blocks = (uint32_t)v & ~7u; }
@@ -1239,6 +1269,7 @@ void rdr_destroy(rdr_ctx* c) {
     for (HostImage& img : c->images) img.pixels.release();
     c->h_stage.release(); c->h_read.release(); c->h_palette.release(); c->h_cull.release();
     for (int i = 0; i < 10 * RDR_FRAME_SLOTS; i++) if (c->ev_sets[i / 10][i % 10]) (void)hipEventDestroy(c->ev_sets[i / 10][i % 10]);
+    for (int i = 0; i < RDR_FRAME_SLOTS * 2; i++) if (c->tr_ev[i / 2][i % 2]) (void)hipEventDestroy(c->tr_ev[i / 2][i % 2]);
     if (c->ev_pairs) (void)hipEventDestroy(c->ev_pairs);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1764,6 +1795,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         c->slot = slot;
         c->ev = c->ev_sets[slot];
         c->frame_claimed = true;
+        c->tr_host[c->slot][0] = t_enter;
     }
     // this frame writes the buffer set the last frame of its slot used: the sets rotate, the oldest comes to the front
     for (int a = 0; a < RDR_FRAME_SLOTS - 1; a++) {
@@ -1892,8 +1924,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         // The vertex stage needs the pair scan and the frame constants, and only the shading needs the vertex stage: it
         // goes to the stream the 4x rasteriser will take later (idle until the sort is done), beside the pair expansion
         // and the sort instead of in front of them (RDR_VERTEX_STAGE_IN_LINE=1: on the front-end stream, a measurement aid).
-        const char* in_line = getenv("RDR_VERTEX_STAGE_IN_LINE");
-        hipStream_t vs = (in_line && atoi(in_line)) ? c->stream : c->stream3;
+        hipStream_t vs = env_on("RDR_VERTEX_STAGE_IN_LINE") ? c->stream : c->stream3;
         if (vs != c->stream) {
             HIP_TRY(hipEventRecord(c->ev_vertex_in, c->stream));
             HIP_TRY(hipStreamWaitEvent(vs, c->ev_vertex_in, 0));
@@ -1918,7 +1949,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     HIP_TRY(c->d_tile_first.ensure((size_t)n_screen_tiles * 4));
     uint32_t* const list_count = frame_counters(c) + RDR_COUNTER_LISTS / 4u;
     const FragLists L = make_frag_lists(W, H, (int)S, c->d_ofrag_recs.p, c->d_ofrag_cols.p, c->d_pixel_state.as<uint32_t>(), c->d_tile_first.as<uint32_t>(),
-                                        list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
+                                  list_count, list_count + RDR_FRAG_SEGS * RDR_FRAG_CTR_STRIDE);
     int cur = 0;
     RDR_TRY(raster_batch(c, b, &cur, enqueue_shade_setup, fused_classify ? &L : nullptr, true));
     if (blend_view) c->stats.views -= 1;  // the blended draws belong to the main view, already counted
@@ -2032,10 +2063,12 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     c->pending[c->slot].host = c->stats;
     // The frame `lag` calls back has had the whole set-up of the frames since to finish its tail: its results are
     // picked up now, so that it is complete (image, luminance, counters) when this call returns.
+    c->tr_host[c->slot][4] = c->tr_host[c->slot][5] = host_now();
     for (int age = RDR_FRAME_SLOTS - 1; age >= c->lag; age--) {
         const int s = (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS;
         if (!c->pending[s].on) continue;
         HIP_TRY(hipEventSynchronize(c->ev_sets[s][5]));
+        c->tr_host[c->slot][5] = host_now();
         harvest(c, s);
     }
     // With a device destination the call only enqueues; rdr_synchronize(), or the next frame, picks up the luminance
