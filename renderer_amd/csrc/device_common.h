@@ -188,6 +188,9 @@ RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, 
     }
 }
 
+// Products of two values below 2^23 (image sizes, rows, faces): the 24-bit multiplier issues at full rate, the 32-bit
+// one at a quarter of it.
+RDR_DEV int mul24(int a, int b) { return __mul24(a, b); }
 // Variants for shading, where the result is continuous in the direction (filtering is seamless across cube edges, so
 // which of two tied faces is chosen does not show): the hardware's cube-map instructions select the face by the same
 // rule as cube_face above (z wins ties over y over x) and return sc, tc and twice the major axis; the division is
@@ -213,7 +216,7 @@ RDR_DEV void cube_sample_fast(const DCube& cube, uint32_t level, float dx, float
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
     const int i0 = min(max((int)fu, -1), r - 1), j0 = min(max((int)fv, -1), r - 1);
-    const RDR_GLOBAL uint32_t* row = px + ((face * pitch + j0 + 1) * pitch + i0 + 1);
+    const RDR_GLOBAL uint32_t* row = px + (mul24(mul24(face, pitch) + j0 + 1, pitch) + i0 + 1);
     uint32_t q00, q10, q01, q11;
     load_pair(row, q00, q10);
     load_pair(row + pitch, q01, q11);
@@ -242,7 +245,7 @@ RDR_DEV void cube_sample_quad(const DCube& cube, uint32_t level, float dx, float
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
     const int i0 = min(max((int)fu, -1), r - 1), j0 = min(max((int)fv, -1), r - 1);
-    const rdr_uint4_t q = px[(face * pitch + j0 + 1) * pitch + i0 + 1];
+    const rdr_uint4_t q = px[mul24(mul24(face, pitch) + j0 + 1, pitch) + i0 + 1];
     float c00[3], c10[3], c01[3], c11[3];
     unpack_r11g11b10(q.x, c00[0], c00[1], c00[2]);
     unpack_r11g11b10(q.y, c10[0], c10[1], c10[2]);
@@ -278,9 +281,10 @@ RDR_DEV int wrap_index(int i, int n, uint32_t mode) {
 RDR_DEV uint32_t tex_level_offset(const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level) {
     const uint32_t flags = t.info >> 5;
     if (flags & RDR_TEXD_POW2_SQUARE) {
-        // sum_{i<level} 4^(n-i) = (4^(n+1) - 4^(n-level+1)) / 3 with w = h = 2^n
+        // sum_{i<level} 4^(n-i) with w = h = 2^n: 4^(n-level+1) * (4^level - 1) / 3, and (4^level - 1) / 3 is `level`
+        // ones in the even bit positions (no division, no multiplication)
         const uint32_t n = 31u - (uint32_t)__clz((int)(t.wh & 0xFFFFu));
-        return ((4u << (2u * n)) - (4u << (2u * (n - level)))) / 3u;
+        return (0x55555555u & ((1u << (2u * level)) - 1u)) << (2u * (n - level + 1u));
     }
     return as_global(table)[t.info >> 16].level_offset[level];
 }
@@ -319,8 +323,9 @@ RDR_DEV void tex_level_taps(const DTexDesc& t, const DTexture* __restrict__ tabl
     int i0, i1, j0, j1;
     tex_axis(u, w, (flags >> 2) & 3u, i0, i1, o.a);
     tex_axis(v, h, (flags >> 4) & 3u, j0, j1, o.b);
-    o.o00 = base + (uint32_t)(j0 * w + i0); o.o10 = base + (uint32_t)(j0 * w + i1);
-    o.o01 = base + (uint32_t)(j1 * w + i0); o.o11 = base + (uint32_t)(j1 * w + i1);
+    const int r0 = mul24(j0, w), r1 = mul24(j1, w);  // sizes are below 2^16
+    o.o00 = base + (uint32_t)(r0 + i0); o.o10 = base + (uint32_t)(r0 + i1);
+    o.o01 = base + (uint32_t)(r1 + i0); o.o11 = base + (uint32_t)(r1 + i1);
 }
 // texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2)
 RDR_DEV void tex_taps(const DTexDesc& t, const DTexture* __restrict__ table, float u, float v, float dudx, float dvdx, float dudy, float dvdy,

@@ -32,6 +32,17 @@
 #include "kernels.h"
 #include "raster_common.h"
 
+// Diagnostic builds only: every lane of a gather reads the same place (bit 0 material textures, bit 1 point-light
+// shadow maps, bit 2 image-based lighting, bit 3 cascades): the arithmetic stays, the memory path sees one line per
+// load. The frames are wrong; the kernel's time tells what the scattered addresses cost.
+#ifndef RDR_DIAG_COALESCE
+#define RDR_DIAG_COALESCE 0
+#endif
+#define RDR_DIAG_ZERO(fr) ((uint32_t)(fr).n_cascades >> 16)  // zero, but not to the compiler
+#ifndef RDR_BRDF_ONE_RCP
+#define RDR_BRDF_ONE_RCP 1  // 0: a reciprocal per denominator of the specular term (measurement aid)
+#endif
+
 namespace {
 
 RDR_DEV float interp3(const float lam[3], float a0, float a1, float a2) { return fmaf(lam[2], a2, fmaf(lam[1], a1, lam[0] * a0)); }
@@ -49,14 +60,14 @@ RDR_DEV void load_pair_f(const RDR_GLOBAL float* p, float& a, float& b) {
 }
 // `map` is the cascade's (res + 4)^2 image with two texels of 1.0 around the interior: a footprint that leaves the
 // map reads the border value there, as CLAMP_TO_BORDER does, without a test.
-RDR_DEV float shadow_pcf(const RDR_GLOBAL float* __restrict__ map, int res, float s, float t, float ref) {
+RDR_DEV float shadow_pcf(const RDR_GLOBAL float* __restrict__ map, int res, float s, float t, float ref, uint32_t coalesce_mask = ~0u) {
 #pragma clang fp contract(fast)
     const float tu = s * (float)res - 0.5f, tv = t * (float)res - 0.5f;
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
     const int i0 = (int)clampf(fu, -2.0f, (float)res), j0 = (int)clampf(fv, -2.0f, (float)res);
     const int pitch = res + 4;
-    const RDR_GLOBAL float* row = map + ((j0 + 2) * pitch + i0 + 2);
+    const RDR_GLOBAL float* row = map + (coalesce_mask & (uint32_t)(mul24(j0 + 2, pitch) + i0 + 2));
     float d00, d10, d01, d11;
     load_pair_f(row, d00, d10);
     load_pair_f(row + pitch, d01, d11);
@@ -78,7 +89,7 @@ RDR_DEV float shadow_cube(const DFrame& fr, uint32_t slot, float rx, float ry, f
     const float fu = floorf(tu), fv = floorf(tv);
     const float a = tu - fu, b = tv - fv;
     const int i0 = min(max((int)fu, -1), res - 1), j0 = min(max((int)fv, -1), res - 1);
-    const RDR_GLOBAL float* row = map + (need ? (face * pitch + j0 + 1) * pitch + i0 + 1 : 0);
+    const RDR_GLOBAL float* row = map + (((RDR_DIAG_COALESCE & 2) ? RDR_DIAG_ZERO(fr) : ~0u) & (uint32_t)(need ? mul24(mul24(face, pitch) + j0 + 1, pitch) + i0 + 1 : 0));
     float d00, d10, d01, d11;
     load_pair_f(row, d00, d10);
     load_pair_f(row + (need ? pitch : 0), d01, d11);
@@ -131,8 +142,14 @@ RDR_DEV void brdf_eval2(const BrdfFrag& f, v2f LL, v2f NL, v2f VL, v2f& r, v2f& 
     const v2f gden = NL1 * f.omk + f.k;
     v2f sden = f.c4 * NL1;
     sden = v2(fmaxf(sden.x, 1e-5f), fmaxf(sden.y, 1e-5f));
+#if RDR_BRDF_ONE_RCP
+    // D * G / (4 N.V N.L): one reciprocal of the product of the three denominators (each at least 1e-11: no underflow)
+    const v2f den = dd * gden * sden;
+    const v2f spec = (f.a2 * f.gv) * NL1 * v2(fast_rcp(den.x), fast_rcp(den.y));
+#else
     const v2f G = NL1 * v2(fast_rcp(gden.x), fast_rcp(gden.y)) * f.gv;
     const v2f spec = f.a2 * v2(fast_rcp(dd.x), fast_rcp(dd.y)) * G * v2(fast_rcp(sden.x), fast_rcp(sden.y));
+#endif
     const v2f x = 1.0f - HdotV;
     const v2f x2 = x * x, x5 = x2 * x2 * x;
     const v2f NdotL = v2(fmaxf(NL.x, 0.0f), fmaxf(NL.y, 0.0f));
@@ -332,6 +349,10 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
 #define RDR_TEX_FENCE() do { if (RDR_TEX_SERIAL) asm volatile("" ::: "memory"); } while (0)
             TexRaw r0, r1, r2, r3, r4;
             const bool any_emissive = __any(has_emissive) != 0;
+            if (RDR_DIAG_COALESCE & 1) {
+                const uint32_t z = RDR_DIAG_ZERO(fr);
+                for (int l = 0; l < 2; l++) { taps0.lv[l].o00 &= z; taps0.lv[l].o01 &= z; }
+            }
             tex_issue(td[1], taps0, r1);
             if (!RDR_TEX_SERIAL) { tex_issue(td[0], taps0, r0); tex_issue(td[2], taps0, r2); }
             tex_resolve<7>(srgb, td[1], taps0, r1, t);
@@ -414,8 +435,9 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const float fl = floorf(lod), ff = lod - fl;
         const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, fr.prefiltered.levels - 1u);
         float s0[3], s1[3], irr[3], lut[2];
-        cube_sample_quad(fr.prefiltered, l0, Rv.x, Rv.y, Rv.z, s0);
-        cube_sample_quad(fr.prefiltered, l1, Rv.x, Rv.y, Rv.z, s1);
+        const float dz = (RDR_DIAG_COALESCE & 4) ? (float)RDR_DIAG_ZERO(fr) : 1.0f;  // 0: every lane looks along +x
+        cube_sample_quad(fr.prefiltered, l0, (RDR_DIAG_COALESCE & 4) ? 1.0f : Rv.x, Rv.y * dz, Rv.z * dz, s0);
+        cube_sample_quad(fr.prefiltered, l1, (RDR_DIAG_COALESCE & 4) ? 1.0f : Rv.x, Rv.y * dz, Rv.z * dz, s1);
         {
             const int w = (int)fr.lut_w, h = (int)fr.lut_h;
             int i0, i1, j0, j1;
@@ -423,7 +445,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
             tex_axis(NdotV, w, 0u, i0, i1, a);
             tex_axis(roughness, h, 0u, j0, j1, b);
             // footprint-major table: the four texels of the (wrapped) footprint at (i0, j0) are one 16-byte entry
-            const rdr_uint4_t q = ((const RDR_GLOBAL rdr_uint4_t*)as_global((const uint32_t*)fr.lut))[j0 * w + i0];
+            const rdr_uint4_t q = ((const RDR_GLOBAL rdr_uint4_t*)as_global((const uint32_t*)fr.lut))[((RDR_DIAG_COALESCE & 4) ? RDR_DIAG_ZERO(fr) : ~0u) & (uint32_t)(mul24(j0, w) + i0)];
             const uint32_t q00 = q.x, q10 = q.y, q01 = q.z, q11 = q.w;
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -433,7 +455,7 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
                 lut[k] = (1.0f - b) * top + b * bot;
             }
         }
-        cube_sample_quad(fr.irradiance, 0, N.x, N.y, N.z, irr);
+        cube_sample_quad(fr.irradiance, 0, (RDR_DIAG_COALESCE & 4) ? 1.0f : N.x, N.y * dz, N.z * dz, irr);
         const float x = 1.0f - clampf(NdotV, 0.0f, 1.0f);
         const float x2 = x * x, x5 = x2 * x2 * x;
         const float F[3] = {F0.x + (1.0f - F0.x) * x5, F0.y + (1.0f - F0.y) * x5, F0.z + (1.0f - F0.z) * x5};
@@ -495,7 +517,12 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const v2f ls = v2(unit0 ? __builtin_amdgcn_rsqf(d2.x) : 1.0f, unit1 ? __builtin_amdgcn_rsqf(d2.y) : 1.0f);
         v2f r, g, b;
         brdf_eval2(bf, v2(unit0 ? 1.0f : d2.x, unit1 ? 1.0f : d2.y), nl * ls, vl * ls, r, g, b);
+#if RDR_BRDF_ONE_RCP
+        const v2f att = v2(unit0 ? ls.x * ls.x : fast_rcp(d2.x), unit1 ? ls.y * ls.y : fast_rcp(d2.y));  // 1 / distance^2
+        const v2f w = v2(on0 ? att.x * sh[0] : 0.0f, on1 ? att.y * sh[1] : 0.0f);  // attenuation x shadow
+#else
         const v2f w = v2(on0 ? fast_rcp(d2.x) * sh[0] : 0.0f, on1 ? fast_rcp(d2.y) * sh[1] : 0.0f);  // attenuation x shadow
+#endif
         LoR += r * (v2(pl.ix[0], pl.ix[1]) * w);
         LoG += g * (v2(pl.iy[0], pl.iy[1]) * w);
         LoB += b * (v2(pl.iz[0], pl.iz[1]) * w);
@@ -518,7 +545,8 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
             if (fminf(ls0, ls1) > 1e-2f && fmaxf(ls0, ls1) < 1.0f - 1e-2f) break;
         }
         const int layer = min(split, ncasc - 1);
-        const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * (res + 4) * (res + 4), res, ls0, ls1, ls2);
+        const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * (res + 4) * (res + 4), res, ls0, ls1, ls2,
+                                                (RDR_DIAG_COALESCE & 8) ? RDR_DIAG_ZERO(fr) : ~0u);
         if (shadowTest > 1e-3f) {
             const F3 r = brdf_eval(bf, 1.0f, dir_nl, dot3f(V, dirL));
             Lo = Lo + f3(r.x * (fr.dir_I[0] * shadowTest), r.y * (fr.dir_I[1] * shadowTest), r.z * (fr.dir_I[2] * shadowTest));
