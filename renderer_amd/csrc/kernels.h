@@ -30,6 +30,12 @@ uint32_t sort_chunks(uint32_t n);
 size_t sort_hist_words(uint32_t n);
 int launch_radix_sort(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, uint32_t key_bits, uint32_t* hist,
                       uint32_t* scan_scratch, uint32_t* d_dummy_total);
+// the same order from one launch per digit (and one in front that counts the digits and clears `clear` words from
+// `to_clear` on): see kernels_sort.hip. n < 2^30. `ghist_zeroed`: the first 4 x 512 words of `work` are already zero.
+size_t sort_onesweep_work_bytes(uint32_t n);
+#define RDR_SORT_ONESWEEP_HIST_WORDS (4u * 512u)
+int launch_radix_sort_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, uint32_t key_bits, void* work, uint32_t* epoch,
+                               uint32_t* to_clear, uint32_t clear, uint32_t* error, bool ghist_zeroed);
 
 // kernels_draws.hip
 size_t draw_list_scratch_words(uint32_t n_slots, uint32_t longest_sorted);
@@ -42,9 +48,10 @@ void launch_draw_lists(hipStream_t s, const DDrawList* lists, uint32_t n_lists, 
 void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const uint32_t* draw_first, uint32_t n_draws, uint32_t n_inst,
                   const DPrim* prims, const void* pos, const uint32_t* idx, DTriRec* recs, uint32_t* pair_count, uint32_t* n_binned,
                   const uint32_t* chunk_first, uint32_t n_chunks, const void* chunk_bb, uint8_t* chunk_flags);
+// `zero` / `n_zero` (at most 4096 words): cleared by the first block on the way, for the kernel behind this one
 void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const uint32_t* pair_offset, uint32_t n_inst, uint32_t n_pairs,
-                 uint32_t* keys, uint32_t* vals);
-void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_ranges, uint32_t n_tiles);
+                 uint32_t* keys, uint32_t* vals, uint32_t* zero = nullptr, uint32_t n_zero = 0);
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_ranges, uint32_t n_tiles, bool cleared = false);
 // tiles [first_tile, end_tile) hold the views of one sample count, the first of which is view first_view
 struct RasterRange { uint32_t first_tile, end_tile, first_view; };
 // the views of one rasteriser launch, passed by value in the kernel arguments

@@ -396,8 +396,10 @@ RDR_DEV uint32_t wave_upper_index(const uint32_t* __restrict__ offset, uint32_t 
 #define EMIT_SPAN 2048u
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) k_emit(const DView* __restrict__ views, const DTriRec* __restrict__ recs,
                                               const uint32_t* __restrict__ pair_offset, uint32_t n_inst, uint32_t n_pairs,
-                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ zero, uint32_t n_zero) {
     __shared__ uint32_t lds_off[EMIT_SPAN];
+    if (blockIdx.x == 0u)
+        for (uint32_t i = threadIdx.x; i < n_zero; i += 256u) zero[i] = 0u;
     __shared__ uint32_t lds_end[2];
     const uint32_t p0 = blockIdx.x * 256u, p = p0 + threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -874,13 +876,13 @@ void launch_setup(hipStream_t s, const DView* views, const DDraw* draws, const u
                        (const float4*)pos, idx, recs, pair_count, n_binned, chunk_first, chunk_flags);
 }
 void launch_emit(hipStream_t s, const DView* views, const DTriRec* recs, const uint32_t* pair_offset, uint32_t n_inst, uint32_t n_pairs,
-                 uint32_t* keys, uint32_t* vals) {
+                 uint32_t* keys, uint32_t* vals, uint32_t* zero, uint32_t n_zero) {
     if (!n_pairs) return;
-    hipLaunchKernelGGL(k_emit, dim3((n_pairs + 255) / 256), dim3(256), 0, s, views, recs, pair_offset, n_inst, n_pairs, keys, vals);
+    hipLaunchKernelGGL(k_emit, dim3((n_pairs + 255) / 256), dim3(256), 0, s, views, recs, pair_offset, n_inst, n_pairs, keys, vals, zero, n_zero);
 }
 // `tile_ranges` = tile_start[n_tiles] followed by tile_end[n_tiles]: cleared with one fill
-void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_ranges, uint32_t n_tiles) {
-    (void)hipMemsetAsync(tile_ranges, 0, (size_t)n_tiles * 8, s);
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_pairs, uint32_t* tile_ranges, uint32_t n_tiles, bool cleared) {
+    if (!cleared || !n_pairs) (void)hipMemsetAsync(tile_ranges, 0, (size_t)n_tiles * 8, s);
     if (!n_pairs) return;
     hipLaunchKernelGGL(k_ranges, dim3((n_pairs + 255) / 256), dim3(256), 0, s, keys, n_pairs, tile_ranges, tile_ranges + n_tiles);
 }

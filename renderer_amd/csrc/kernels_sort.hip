@@ -173,6 +173,168 @@ __global__ void __launch_bounds__(64) k_sort_scatter(const uint32_t* __restrict_
     }
 }
 
+
+// ---- radix sort in one launch per digit ----------------------------------------------------------------------------
+// The pair sort of the binning stage is a handful of small dependent kernels, and what it costs is their number. Here a
+// digit pass is ONE kernel: a 512-thread block owns OS_CHUNK consecutive pairs, counts its digits, and gets the number
+// of pairs of every digit in the chunks before it by looking back over the counts those blocks publish (a chained
+// scan: a block first publishes its own counts, then walks towards chunk 0 adding up counts until it meets a block
+// that already knows its running total, then publishes its own running total). One kernel in front of the passes
+// (k_os_hist) counts every digit of every pass once, which gives each pass the first position of each digit.
+//
+// A status word is epoch << 32 | state << 30 | count: one 64-bit store publishes it, and a word left by an earlier
+// sort is recognised by its epoch, so the status array is never cleared. Blocks are dispatched in index order and
+// only wait for blocks with smaller indices; the wait is bounded all the same (OS_SPIN_LIMIT reads of one word), and a
+// block that gives up raises *error and stores nothing outside the output arrays.
+#define OS_THREADS 512
+#define OS_WAVES (OS_THREADS / 64)
+#define OS_ROUNDS 8
+#define OS_CHUNK (OS_THREADS * OS_ROUNDS)  // 4096 pairs
+#define OS_MAX_PASSES 4
+#define OS_AGGREGATE 1ull
+#define OS_PREFIX 2ull
+#define OS_SPIN_LIMIT (1u << 20)
+#define OS_WINDOW 8  // status words of that many chunks fetched together when looking back
+
+// Digit counts of all passes (ghist[pass * SORT_MAX_BINS + digit], zero on entry) and, while the keys go by, the tile
+// ranges cleared for k_ranges (`clear` words from `to_clear` on).
+__global__ void __launch_bounds__(OS_THREADS) k_os_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t passes, uint32_t bits,
+                                                       uint32_t* __restrict__ ghist, uint32_t* __restrict__ to_clear, uint32_t clear) {
+    __shared__ uint32_t hist[OS_MAX_PASSES * SORT_MAX_BINS];
+    for (uint32_t i = threadIdx.x; i < passes * SORT_MAX_BINS; i += OS_THREADS) hist[i] = 0u;
+    for (uint32_t i = blockIdx.x * OS_THREADS + threadIdx.x; i < clear; i += gridDim.x * OS_THREADS) to_clear[i] = 0u;
+    __syncthreads();
+    const uint32_t mask = (1u << bits) - 1u, lane = threadIdx.x & 63u, base = blockIdx.x * OS_CHUNK;
+    uint32_t k[OS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < OS_ROUNDS; r++) {
+        const uint32_t i = base + r * OS_THREADS + threadIdx.x;
+        k[r] = i < n ? keys[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < OS_ROUNDS; r++) {
+        const bool valid = base + r * OS_THREADS + threadIdx.x < n;  // a prefix of the lanes
+        for (uint32_t p = 0; p < passes; p++) {
+            // Neighbouring pairs are tiles of one triangle: their upper digits are mostly equal, and 64 additions to
+            // one LDS word take 64 turns. The first lane of every run of equal digits adds the run's length instead.
+            const uint32_t digit = (k[r] >> (p * bits)) & mask;
+            const uint32_t left = (uint32_t)__shfl_up((int)digit, 1);
+            const unsigned long long heads = __ballot(valid && (lane == 0u || digit != left));
+            const uint32_t n_valid = (uint32_t)__popcll(__ballot(valid));
+            if (valid && ((heads >> lane) & 1ull)) {
+                const unsigned long long later = lane == 63u ? 0ull : heads >> (lane + 1u);  // heads of the runs behind this one
+                const uint32_t len = later ? (uint32_t)__ffsll((long long)later) : n_valid - lane;
+                atomicAdd(&hist[p * SORT_MAX_BINS + digit], len);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < passes * SORT_MAX_BINS; i += OS_THREADS)
+        if (hist[i]) atomicAdd(&ghist[i], hist[i]);
+}
+
+// One digit pass. ghist: this pass's digit counts over all keys. status: [chunk][SORT_MAX_BINS] words, see above.
+__global__ void __launch_bounds__(OS_THREADS) k_os_pass(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t shift,
+                                                       uint32_t bits, const uint32_t* __restrict__ ghist, unsigned long long* status, uint32_t epoch,
+                                                       uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals, uint32_t* error) {
+    __shared__ uint32_t offs[OS_WAVES][SORT_MAX_BINS];  // per wave: running count of a digit, later its first position
+    __shared__ uint32_t ws[OS_WAVES];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t bins = 1u << bits;
+    for (uint32_t i = tid; i < OS_WAVES * SORT_MAX_BINS; i += OS_THREADS) (&offs[0][0])[i] = 0u;
+    // wave w owns pairs [base + w * 64 * OS_ROUNDS, + 64 * OS_ROUNDS) of the chunk, in rounds of 64: pair order is (wave, round, lane)
+    const uint32_t base = blockIdx.x * OS_CHUNK + wave * (64u * OS_ROUNDS);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t kreg[OS_ROUNDS], vreg[OS_ROUNDS], rank[OS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < OS_ROUNDS; r++) {
+        const uint32_t i = base + r * 64 + lane;
+        kreg[r] = i < n ? keys[i] : 0u;
+        vreg[r] = i < n ? vals[i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < OS_ROUNDS; r++) {
+        const bool valid = base + r * 64 + lane < n;
+        const uint32_t digit = (kreg[r] >> shift) & (bins - 1u);
+        unsigned long long same = __ballot(valid);  // lanes holding the same digit as this lane
+        for (uint32_t b = 0; b < bits; b++) {
+            const unsigned long long bal = __ballot(valid && ((digit >> b) & 1u));
+            same &= ((digit >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & lt_mask);
+        rank[r] = valid ? offs[wave][digit] + before : 0u;
+        // A wave's row of counts is its own, and LDS takes a wave's instructions in order: waiting for the reads to
+        // return keeps them in front of the leaders' additions, no block-wide barrier needed.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (valid && before == 0u) offs[wave][digit] += (uint32_t)__popcll(same);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // thread d looks after digit d: the waves' counts become the waves' first positions inside the chunk's run of d
+    uint32_t count = 0u;
+    if (tid < bins) {
+#pragma unroll
+        for (int w = 0; w < OS_WAVES; w++) { const uint32_t c = offs[w][tid]; offs[w][tid] = count; count += c; }
+    }
+    const unsigned long long tag = (unsigned long long)epoch << 32;
+    unsigned long long* const mine = status + (size_t)blockIdx.x * SORT_MAX_BINS + tid;
+    if (tid < bins) __hip_atomic_store(mine, tag | ((blockIdx.x ? OS_AGGREGATE : OS_PREFIX) << 30) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // first position of digit d in the output: the keys with a smaller digit (exclusive scan of the totals over the block)
+    const uint32_t total = tid < bins ? ghist[tid] : 0u;
+    uint32_t first;
+    {
+        const uint32_t inc = wave_inclusive_scan(total, (int)lane);
+        if (lane == 63u) ws[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0u;
+#pragma unroll
+        for (int w = 0; w < OS_WAVES; w++) if ((uint32_t)w < wave) before += ws[w];
+        first = before + inc - total;
+    }
+    // pairs of digit d in the chunks before this one
+    uint32_t earlier = 0u;
+    if (tid < bins && blockIdx.x) {
+        // OS_WINDOW chunks at a time, nearest first: their words are fetched together (one trip to the cache), then taken
+        // in order up to the first that is not there yet (fetched again, with what lies beyond it) or knows its total
+        uint32_t spins = 0u, c = blockIdx.x;  // chunks [0, c) are still to be accounted for
+        bool done = false;
+        while (!done && c) {
+            unsigned long long w[OS_WINDOW];
+#pragma unroll
+            for (int j = 0; j < OS_WINDOW; j++)
+                w[j] = (uint32_t)j < c ? __hip_atomic_load(status + (size_t)(c - 1u - (uint32_t)j) * SORT_MAX_BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+            for (int j = 0; j < OS_WINDOW; j++) {
+                if (done || (uint32_t)j >= c) break;
+                const uint32_t state = (uint32_t)(w[j] >> 30) & 3u;
+                if ((w[j] >> 32) != epoch || !state) {  // not published yet
+                    c -= (uint32_t)j;
+                    if (++spins > OS_SPIN_LIMIT) { atomicOr(error, 1u); done = true; }
+                    else __builtin_amdgcn_s_sleep(1);
+                    goto again;
+                }
+                earlier += (uint32_t)(w[j] & 0x3FFFFFFFull);
+                if (state == (uint32_t)OS_PREFIX) done = true;
+            }
+            if (!done) c -= min(c, (uint32_t)OS_WINDOW);
+        again:;
+        }
+        __hip_atomic_store(mine, tag | (OS_PREFIX << 30) | (unsigned long long)(earlier + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < bins) {
+#pragma unroll
+        for (int w = 0; w < OS_WAVES; w++) offs[w][tid] += first + earlier;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < OS_ROUNDS; r++) {
+        if (base + r * 64 + lane >= n) continue;
+        const uint32_t pos = offs[wave][(kreg[r] >> shift) & (bins - 1u)] + rank[r];
+        if (pos < n) { out_keys[pos] = kreg[r]; out_vals[pos] = vreg[r]; }  // pos >= n only after a failed wait
+    }
+}
+
 }  // namespace
 
 size_t scan_scratch_words(uint32_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1; }
@@ -208,6 +370,32 @@ int launch_radix_sort(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint3
         launch_exclusive_scan(s, hist, hist, bins * nchunks, scan_scratch, d_dummy_total);
         hipLaunchKernelGGL(k_sort_scatter, dim3(nchunks), dim3(64), 0, s, (const uint32_t*)keys[cur], (const uint32_t*)vals[cur], n, shift, bits,
                            (const uint32_t*)hist, nchunks, keys[cur ^ 1], vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// The same sort with one launch per digit plus one in front (see k_os_pass). n < 2^30. `work` holds
+// sort_onesweep_work_bytes(n) bytes, of which the status words must have been zero when the buffer was new (they are
+// not cleared between sorts); *epoch is the caller's running pass number for this buffer (it goes up by one per digit;
+// the caller clears the buffer and the counter long before 2^32). `to_clear` / `clear`: words
+// zeroed on the way (the tile ranges k_ranges fills), saving the fill a launch. *error is set to non-zero if a block
+// gave up waiting (it never happens in a working launch; the result is then undefined but in bounds).
+uint32_t sort_onesweep_chunks(uint32_t n) { return (n + OS_CHUNK - 1) / OS_CHUNK; }
+size_t sort_onesweep_work_bytes(uint32_t n) { return (size_t)OS_MAX_PASSES * SORT_MAX_BINS * 4 + (size_t)sort_onesweep_chunks(n) * SORT_MAX_BINS * 8; }
+int launch_radix_sort_onesweep(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, uint32_t key_bits, void* work, uint32_t* epoch,
+                               uint32_t* to_clear, uint32_t clear, uint32_t* error, bool ghist_zeroed) {
+    if (n == 0) return 0;
+    const uint32_t passes = (key_bits + 8) / 9, bits = (key_bits + passes - 1) / passes, chunks = sort_onesweep_chunks(n);
+    uint32_t* ghist = (uint32_t*)work;
+    unsigned long long* status = (unsigned long long*)(ghist + OS_MAX_PASSES * SORT_MAX_BINS);
+    if (!ghist_zeroed) (void)hipMemsetAsync(ghist, 0, (size_t)passes * SORT_MAX_BINS * 4, s);
+    hipLaunchKernelGGL(k_os_hist, dim3(chunks), dim3(OS_THREADS), 0, s, (const uint32_t*)keys[0], n, passes, bits, ghist, to_clear, clear);
+    int cur = 0;
+    for (uint32_t p = 0; p < passes; p++) {
+        ++*epoch;  // the caller clears the status words before the counter wraps
+        hipLaunchKernelGGL(k_os_pass, dim3(chunks), dim3(OS_THREADS), 0, s, (const uint32_t*)keys[cur], (const uint32_t*)vals[cur], n, p * bits, bits,
+                           (const uint32_t*)(ghist + p * SORT_MAX_BINS), status, *epoch, keys[cur ^ 1], vals[cur ^ 1], error);
         cur ^= 1;
     }
     return cur;

@@ -36,6 +36,7 @@ namespace {
 #define RDR_COUNTER_LISTS RDR_COUNTER_BYTES  // byte offset of the list counters inside a slot's block
 #define RDR_COUNTER_SLOT_BYTES (RDR_COUNTER_BYTES + (RDR_FRAG_SEGS + 8u) * RDR_FRAG_CTR_STRIDE * 4u)  // what a frame zeroes
 #define RDR_COUNTER_LUM 4u  // word of the scalar counters that the luminance reduction writes its result to
+#define RDR_COUNTER_SORT_FAILED 6u  // word the pair sort raises when one of its blocks gave up waiting for another
 #define RDR_COUNTER_FRAGS 5u  // word the blended pass counts its fragment-list slots in (zero after the frame's fill)
 #define RDR_FRAME_SLOTS 3  // frames that can be in flight: each has its own buffer set, events, counters and read-back block
 #define RDR_READ_MID ((unsigned)RDR_FRAME_SLOTS * RDR_COUNTER_BYTES)
@@ -211,6 +212,9 @@ struct rdr_ctx {
     DevBuf d_frags, d_frag_col, d_frag_head, d_tile_slots;
     // opaque pass: fragment records and colours (one list per screen rectangle), per-pixel state, first fragment per tile
     DevBuf d_ofrag_recs, d_ofrag_cols, d_pixel_state, d_tile_first;
+    DevBuf d_sort_work;      // digit counts + status words of the pair sort (launch_radix_sort_onesweep)
+    uint32_t sort_epoch = 0; // its running pass number
+    bool sort_failed = false;
     // The last frame's 4x rasteriser stored depth only in the tiles the blended pass works on (nothing else in a frame
     // reads the main view's depth): rdr_read_depth first runs the rasteriser over the other tiles again, from the
     // frame's triangle records and sorted tile lists, which stay as they are until the slot's next frame.
@@ -280,6 +284,9 @@ struct rdr_ctx {
 };
 
 namespace {
+
+// measurement switches: set and not 0
+bool env_on(const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; }
 
 double host_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -612,6 +619,8 @@ void harvest(rdr_ctx* c, int slot) {
     rdr_frame_stats st = c->pending[slot].host;
     const uint8_t* rd = c->h_read.as<uint8_t>() + (size_t)slot * RDR_COUNTER_BYTES;
     memcpy(&c->last_avg_log_lum, rd + 4 * RDR_COUNTER_LUM, 4);
+    uint32_t sort_word = 0; memcpy(&sort_word, rd + 4 * RDR_COUNTER_SORT_FAILED, 4);
+    if (sort_word) c->sort_failed = true;
     uint32_t binned = 0, chunks_culled = 0;
     for (uint32_t k = 0; k < RDR_BINNED_SLOTS; k++) {
         const uint32_t* w = (const uint32_t*)(rd + 64 + k * 128);
@@ -803,16 +812,33 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
         HIP_TRY(c->d_keys[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
         HIP_TRY(c->d_vals[k].ensure(std::max<size_t>(n_pairs, 1) * 4));
     }
-    HIP_TRY(c->d_hist.ensure((sort_hist_words(n_pairs) + 16) * 4));
-    HIP_TRY(c->d_scan.ensure((scan_scratch_words((uint32_t)sort_hist_words(n_pairs)) + scan_scratch_words(n_inst) + 16) * 4));
-    launch_emit(c->stream, c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(), n_inst, n_pairs,
-                c->d_keys[0].as<uint32_t>(), c->d_vals[0].as<uint32_t>());
     uint32_t key_bits = 1;
     while ((1ull << key_bits) <= n_tiles) key_bits++;
     uint32_t* keys[2] = {c->d_keys[0].as<uint32_t>(), c->d_keys[1].as<uint32_t>()};
     uint32_t* vals[2] = {c->d_vals[0].as<uint32_t>(), c->d_vals[1].as<uint32_t>()};
-    const int cur = launch_radix_sort(c->stream, keys, vals, n_pairs, key_bits, c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(), counters + 2);
-    launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), n_tiles);
+    int cur;
+    // Pair expansion, then the sort: one launch per digit behind one that counts the digits (and clears the tile ranges
+    // on the way), five launches from the pair count to the sorted lists. RDR_SORT_CLASSIC=1: the four-kernel passes
+    // (count, two-level scan, scatter), a measurement aid and the path for more than 2^30 pairs.
+    if (n_pairs < (1u << 30) && !env_on("RDR_SORT_CLASSIC")) {
+        const size_t need = sort_onesweep_work_bytes(n_pairs);
+        if (c->d_sort_work.cap < need || c->sort_epoch > 0xFFFF0000u) {
+            HIP_TRY(c->d_sort_work.ensure(need));
+            HIP_TRY(hipMemsetAsync(c->d_sort_work.p, 0, c->d_sort_work.cap, c->stream));  // no status word of an earlier sort
+            c->sort_epoch = 0u;
+        }
+        launch_emit(c->stream, c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(), n_inst, n_pairs,
+                    keys[0], vals[0], c->d_sort_work.as<uint32_t>(), RDR_SORT_ONESWEEP_HIST_WORDS);
+        cur = launch_radix_sort_onesweep(c->stream, keys, vals, n_pairs, key_bits, c->d_sort_work.p, &c->sort_epoch, c->d_tile_start.as<uint32_t>(),
+                                         n_tiles * 2u, counters + RDR_COUNTER_SORT_FAILED, n_pairs != 0u);
+        launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), n_tiles, true);
+    } else {
+        HIP_TRY(c->d_hist.ensure((sort_hist_words(n_pairs) + 16) * 4));
+        HIP_TRY(c->d_scan.ensure((scan_scratch_words((uint32_t)sort_hist_words(n_pairs)) + scan_scratch_words(n_inst) + 16) * 4));
+        launch_emit(c->stream, c->d_views.as<DView>(), c->d_recs.as<DTriRec>(), c->d_pair_count.as<uint32_t>(), n_inst, n_pairs, keys[0], vals[0]);
+        cur = launch_radix_sort(c->stream, keys, vals, n_pairs, key_bits, c->d_hist.as<uint32_t>(), c->d_scan.as<uint32_t>(), counters + 2);
+        launch_ranges(c->stream, keys[cur], n_pairs, c->d_tile_start.as<uint32_t>(), n_tiles);
+    }
     if (c->trace) { (void)hipEventRecord(c->tr_ev[c->slot][1], c->stream); c->tr_host[c->slot][3] = host_now(); }
     c->stats.triangle_instances += n_inst;
     c->stats.tile_pairs += n_pairs;
@@ -825,9 +851,6 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
 // `after_scan`, if given, runs once set-up and the pair scan are enqueued and before the host waits for the pair
 // count: work enqueued there keeps the GPU busy while the host sizes the pair buffers.
 // `classify`: fragment lists the 4x rasteriser fills for the opaque pass (the frame's main batch), or null.
-// measurement switches: set and not 0
-bool env_on(const char* name) { const char* v = getenv(name); return v && atoi(v) != 0; }
-
 int prev_slot(const rdr_ctx* c) { return (c->slot + RDR_FRAME_SLOTS - 1) % RDR_FRAME_SLOTS; }
 
 // `main_batch`: the frame's own batch. Its shadow-view rasteriser goes to the shading stream (in front of the frame's
@@ -1257,7 +1280,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_env_b, &c->d_irradiance_b, &c->d_prefiltered_b, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
                       &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
-                      &c->d_counters, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_counters, &c->d_sort_work, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1],
                       &c->d_prim_cull, &c->d_models, &c->d_cand, &c->d_draw_scratch, &c->d_irradiance_q, &c->d_prefiltered_q, &c->d_lut_q};
     for (DevBuf* b : bufs) b->release();
@@ -2070,6 +2093,10 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         HIP_TRY(hipEventSynchronize(c->ev_sets[s][5]));
         c->tr_host[c->slot][5] = host_now();
         harvest(c, s);
+    }
+    if (c->sort_failed) {
+        c->sort_failed = false;
+        return fail(c, RDR_ERR_DEVICE, "render_frame: the pair sort of a finished frame gave up waiting for one of its own blocks; that frame is not valid");
     }
     // With a device destination the call only enqueues; rdr_synchronize(), or the next frame, picks up the luminance
     // and the counters.
