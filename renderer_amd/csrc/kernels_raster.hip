@@ -233,6 +233,9 @@ __global__ void __launch_bounds__(256) k_chunk_cull(const DView* __restrict__ vi
         atomicAdd(n_binned + (((blockIdx.x << 2) | (threadIdx.x >> 6)) & (RDR_BINNED_SLOTS - 1u)) * 32u + 4u, (uint32_t)__popcll(m));
 }
 
+#ifndef RDR_SETUP_DIAG_NO_CLIP
+#define RDR_SETUP_DIAG_NO_CLIP 0  // diagnostic builds only: triangles that need clipping are dropped
+#endif
 __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, const DDraw* __restrict__ draws,
                                                const uint32_t* __restrict__ draw_first, uint32_t n_draws, uint32_t n_inst,
                                                const DPrim* __restrict__ prims, const float4* __restrict__ pos,
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(256) k_setup(const DView* __restrict__ views, 
             }
             if (!ok) break;
             count = finish_record<3>(X, Y, 3, cv, vw, d, tri, rec, box_area);
-        } else {
+        } else if (!RDR_SETUP_DIAG_NO_CLIP) {
             int32_t X[RDR_MAX_POLY], Y[RDR_MAX_POLY];
             int n = 3;
             bool ok = true;

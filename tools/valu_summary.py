@@ -42,6 +42,9 @@ for k, c in acc.items():
          "waves_per_launch": round(sum(c["SQ_WAVES"]) / len(c["SQ_WAVES"])) if c.get("SQ_WAVES") else None}
     if busy:
         e["valu_issue_slot_share"] = round(insts * 2.0 / (1024.0 * busy), 4)
+    # against the rate tools/experiments/valu_rate.hip measures on this chip with two or more waves per SIMD: one
+    # fp32 wave-instruction per 1.2 ns and SIMD (packed fp32 no faster per element, reciprocals 3x slower)
+    e["valu_share_of_measured_rate"] = round(insts * 1.2e-3 / 1024.0 / dur[k][1], 4)
     out[k] = e
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
 print()
