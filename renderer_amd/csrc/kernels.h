@@ -26,6 +26,9 @@ void launch_average_luminance(hipStream_t s, const float* loglum, int W, int H, 
 // kernels_sort.hip
 size_t scan_scratch_words(uint32_t n);
 void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch, uint32_t* d_total);
+// the same in one launch; `status` holds scan_chained_words(n) words (8-byte aligned) that are zero before and after
+size_t scan_chained_words(uint32_t n);
+void launch_exclusive_scan_chained(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* status, uint32_t* d_total);
 uint32_t sort_chunks(uint32_t n);
 size_t sort_hist_words(uint32_t n);
 int launch_radix_sort(hipStream_t s, uint32_t* keys[2], uint32_t* vals[2], uint32_t n, uint32_t key_bits, uint32_t* hist,

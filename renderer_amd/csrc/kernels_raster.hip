@@ -460,16 +460,22 @@ __global__ void __launch_bounds__(256) k_ranges(const uint32_t* __restrict__ key
                                                 uint32_t* __restrict__ tile_end) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n_pairs) return;
+    // tile_end follows tile_start: a key that is no tile of the batch (RDR_PAIR_INVALID, the dropped pairs at the end
+    // of the order) owns no range
+    const uint32_t n_tiles = (uint32_t)(tile_end - tile_start);
     const uint32_t k = keys[p];
     const uint32_t prev = p ? keys[p - 1] : RDR_PAIR_INVALID;
     if (k != prev || p == 0) {
-        if (k != RDR_PAIR_INVALID) tile_start[k] = p;
-        if (p && prev != RDR_PAIR_INVALID) tile_end[prev] = p;
+        if (k < n_tiles) tile_start[k] = p;
+        if (p && prev < n_tiles) tile_end[prev] = p;
     }
-    if (p == n_pairs - 1 && k != RDR_PAIR_INVALID) tile_end[k] = n_pairs;
+    if (p == n_pairs - 1 && k < n_tiles) tile_end[k] = n_pairs;
 }
 
 // threads per tile and records staged per pass: single-sampled views (shadow maps), 4x multisampled view
+#ifndef RDR_RASTER1_WAVES
+#define RDR_RASTER1_WAVES 6  // waves per SIMD the single-sample instantiation is compiled for
+#endif
 #ifndef RDR_RASTER_T1
 #define RDR_RASTER_T1 64
 #endif
@@ -547,7 +553,7 @@ __global__ void __launch_bounds__(256) k_view_init(const DView* __restrict__ vie
 // appended to the list of the tile's screen rectangle, a state word per pixel, the position of the tile's first
 // fragment (FragLists, kernels.h; k_frag_classify in kernels_shade.hip does the same from the visibility image).
 template <int S, int T, int RASTER_CHUNK, int TILES, bool CLASSIFY>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(6))) k_raster(const RasterViews tbl, const DTriRec* __restrict__ recs, const uint32_t* __restrict__ sorted_vals,
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(S == 1 ? RDR_RASTER1_WAVES : 6))) k_raster(const RasterViews tbl, const DTriRec* __restrict__ recs, const uint32_t* __restrict__ sorted_vals,
                                               const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_end, const FragLists fl) {
     static_assert(!CLASSIFY || S == 4, "fragment lists are built for the multisampled main view");
     __shared__ uint32_t lds_cls[CLASSIFY ? (256 / 64) + 1 : 1];  // fragments per (pixel group, wave), then the tile's first fragment

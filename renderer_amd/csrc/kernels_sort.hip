@@ -115,6 +115,101 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* in, u
     }
 }
 
+// The scan in ONE launch: a block scans its tile, publishes the tile's sum, learns the sum of everything before the
+// tile by looking back over what the blocks before it published (64 tiles per look, one per lane of its first wave),
+// publishes its own running total and writes its outputs. status[tile] = state << 32 | value (0: nothing yet, 1: the
+// tile's sum, 2: the sum up to and including the tile). The words must be zero when the kernel starts, and are zero
+// again when it ends: every block counts itself out in status[tiles] once it has finished looking back, and the last one
+// to do so clears the lot. Blocks are dispatched in index order and wait only for smaller indices; the wait is bounded
+// (the sums are then wrong: it does not happen in a working launch).
+#define SCAN_SPIN_LIMIT (1u << 20)
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_chained(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* status,
+                                                            uint32_t* __restrict__ out_total) {
+    __shared__ uint32_t ws[SCAN_BLOCK / 64];
+    __shared__ uint32_t lds_before;
+    const uint32_t tile = blockIdx.x, tiles = gridDim.x, base = tile * SCAN_TILE;
+    const uint32_t lane = threadIdx.x & 63u;
+    // The tile is SCAN_ITEMS / 4 rows of SCAN_BLOCK four-element groups; thread t owns group t of every row, so that a
+    // wave reads and writes 1 KiB runs (a thread owning sixteen consecutive elements made every load touch 64 lines).
+    constexpr int ROWS = SCAN_ITEMS / 4;
+    const bool whole = base + SCAN_TILE <= n && ((uintptr_t)in & 15u) == 0u && ((uintptr_t)out & 15u) == 0u;
+    uint32_t v[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const uint32_t i = base + ((uint32_t)r * SCAN_BLOCK + threadIdx.x) * 4u;
+        if (whole) {
+            const rdr_uint4_t q = *(const rdr_uint4_t*)(in + i);
+            v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[r][k] = i + k < n ? in[i + k] : 0u;
+        }
+    }
+    // exclusive position of every group inside the tile: a block scan per row, the rows one after the other
+    uint32_t within[ROWS];
+    uint32_t total = 0u;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        uint32_t row_total;
+        within[r] = total + block_exclusive_scan((v[r][0] + v[r][1]) + (v[r][2] + v[r][3]), ws, row_total);
+        total += row_total;
+    }
+    if (threadIdx.x < 64u) {  // the first wave looks back
+        if (lane == 0u)
+            __hip_atomic_store(status + tile, ((unsigned long long)(tile ? 1u : 2u) << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t before = 0u, c = tile, spins = 0u;  // tiles [0, c) still to be accounted for
+        while (c) {
+            const bool mine = lane < c;  // lane j looks at tile c - 1 - j
+            const unsigned long long w = mine ? __hip_atomic_load(status + (c - 1u - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            const uint32_t state = (uint32_t)(w >> 32);
+            const unsigned long long totals = __ballot(mine && state == 2u), missing = __ballot(mine && state == 0u);
+            // usable: the lanes up to the nearest running total (all of the window if there is none)
+            const unsigned long long upto = totals ? ((totals & (0ull - totals)) << 1) - 1ull : ~0ull;
+            if (missing & upto) {
+                if (++spins > SCAN_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            uint32_t part = (mine && ((upto >> lane) & 1ull)) ? (uint32_t)w : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d);
+            before += part;
+            if (totals) break;
+            c -= min(c, 64u);
+        }
+        if (lane == 0u) {
+            if (tile) __hip_atomic_store(status + tile, (2ull << 32) | (unsigned long long)(before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_before = before;
+            if (tile + 1u == tiles) out_total[0] = before + total;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const uint32_t i = base + ((uint32_t)r * SCAN_BLOCK + threadIdx.x) * 4u;
+        const uint32_t e0 = lds_before + within[r], e1 = e0 + v[r][0], e2 = e1 + v[r][1], e3 = e2 + v[r][2];
+        if (whole) {
+            rdr_uint4_t q;
+            q.x = e0; q.y = e1; q.z = e2; q.w = e3;
+            *(rdr_uint4_t*)(out + i) = q;
+        } else {
+            if (i < n) out[i] = e0;
+            if (i + 1u < n) out[i + 1u] = e1;
+            if (i + 2u < n) out[i + 2u] = e2;
+            if (i + 3u < n) out[i + 3u] = e3;
+        }
+    }
+    // count out; the last block leaves the status words as it found them
+    __shared__ uint32_t lds_last;
+    if (threadIdx.x == 0u) {
+        __threadfence();
+        lds_last = atomicAdd((unsigned int*)(status + tiles), 1u) + 1u == tiles ? 1u : 0u;
+    }
+    __syncthreads();
+    if (lds_last)
+        for (uint32_t i = threadIdx.x; i <= tiles; i += SCAN_BLOCK) status[i] = 0ull;
+}
+
 // ---- radix sort -----------------------------------------------------------
 
 __global__ void __launch_bounds__(64) k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t bins,
@@ -350,6 +445,14 @@ void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, uin
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, scratch, nb, d_total);
         hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n, (const uint32_t*)scratch, out, d_total);
     }
+}
+
+// One launch (k_scan_chained). `status`: scan_chained_words(n) words that are zero, and are zero again afterwards.
+size_t scan_chained_words(uint32_t n) { return 2 * ((size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1); }
+void launch_exclusive_scan_chained(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* status, uint32_t* d_total) {
+    if (n == 0) { (void)hipMemsetAsync(d_total, 0, 4, s); return; }
+    const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_chained, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, n, out, (unsigned long long*)status, d_total);
 }
 
 uint32_t sort_chunks(uint32_t n) { return (n + SORT_CHUNK - 1) / SORT_CHUNK; }

@@ -213,6 +213,7 @@ struct rdr_ctx {
     // opaque pass: fragment records and colours (one list per screen rectangle), per-pixel state, first fragment per tile
     DevBuf d_ofrag_recs, d_ofrag_cols, d_pixel_state, d_tile_first;
     DevBuf d_sort_work;      // digit counts + status words of the pair sort (launch_radix_sort_onesweep)
+    DevBuf d_scan_status;    // status words of the one-launch scans: zero between launches (launch_exclusive_scan_chained)
     uint32_t sort_epoch = 0; // its running pass number
     bool sort_failed = false;
     // The last frame's 4x rasteriser stored depth only in the tiles the blended pass works on (nothing else in a frame
@@ -657,6 +658,15 @@ void harvest(rdr_ctx* c, int slot) {
     c->pending[slot].on = false;
 }
 
+// The status words of the one-launch scans start out zero and every scan leaves them zero: cleared when the buffer grows.
+int ensure_scan_status(rdr_ctx* c, size_t words) {
+    if (c->d_scan_status.cap < words * 4) {
+        HIP_TRY(c->d_scan_status.ensure(words * 4 + 4096));
+        HIP_TRY(hipMemsetAsync(c->d_scan_status.p, 0, c->d_scan_status.cap, c->stream));
+    }
+    return RDR_OK;
+}
+
 // Runs set-up -> bin -> sort for one batch of views. On return the sorted
 // triangle lists of every tile are in d_vals[*cur] / d_tile_start / d_tile_end.
 int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std::function<int()>& after_scan) {
@@ -781,7 +791,12 @@ int bin_batch(rdr_ctx* c, Batch& b, uint32_t* out_tiles, int* out_cur, const std
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + RDR_READ_MID, counters, RDR_COUNTER_BYTES, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_pairs, c->stream));
     if (c->trace) (void)hipEventRecord(c->tr_ev[c->slot][0], c->stream);
-    launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
+    if (!env_on("RDR_SCAN_CLASSIC")) {  // one launch (RDR_SCAN_CLASSIC=1: the two-kernel scan, a measurement aid)
+        RDR_TRY(ensure_scan_status(c, scan_chained_words(n_inst)));
+        launch_exclusive_scan_chained(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan_status.as<uint32_t>(), counters);
+    } else {
+        launch_exclusive_scan(c->stream, c->d_pair_count.as<uint32_t>(), c->d_pair_count.as<uint32_t>(), n_inst, c->d_scan.as<uint32_t>(), counters);
+    }
     if (after_scan) RDR_TRY(after_scan());
     {
         const double t_wait = host_now();
@@ -1280,7 +1295,7 @@ void rdr_destroy(rdr_ctx* c) {
                       &c->d_irradiance, &c->d_prefiltered, &c->d_env_b, &c->d_irradiance_b, &c->d_prefiltered_b, &c->d_lut, &c->d_depth, &c->d_vis, &c->d_samples, &c->d_hdr, &c->d_bloom, &c->d_out,
                       &c->d_loglum, &c->d_lum, &c->d_dir_shadow, &c->d_point_shadow, &c->d_point_static, &c->d_batch_tables,
                       &c->d_recs, &c->d_pair_count, &c->d_scan, &c->d_hist, &c->d_tile_start,
-                      &c->d_counters, &c->d_sort_work, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
+                      &c->d_counters, &c->d_sort_work, &c->d_scan_status, &c->d_ofrag_recs, &c->d_ofrag_cols, &c->d_pixel_state, &c->d_tile_first, &c->d_frags, &c->d_frag_col, &c->d_frag_head, &c->d_tile_slots, &c->d_frame, &c->d_shade_tris, &c->d_rest_pos, &c->d_rest_attr, &c->d_skin_joints,
                       &c->d_skin_weights, &c->d_skin_dst_pal, &c->d_palette, &c->d_chunk_bb, &c->d_chunk_flags, &c->d_keys[0], &c->d_keys[1], &c->d_vals[0], &c->d_vals[1],
                       &c->d_prim_cull, &c->d_models, &c->d_cand, &c->d_draw_scratch, &c->d_irradiance_q, &c->d_prefiltered_q, &c->d_lut_q};
     for (DevBuf* b : bufs) b->release();
@@ -2120,6 +2135,7 @@ int rdr_render_frame(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* out_rgba8,
         // A frame that failed before it took its slot (upload, skinning, target allocation) leaves c->slot naming the
         // frame before it, which is intact and is handed over like the other older ones.
         if (c->frame_claimed) c->pending[c->slot].on = false;
+        if (c->d_scan_status.p) (void)hipMemset(c->d_scan_status.p, 0, c->d_scan_status.cap);  // a scan cut short leaves its status words behind
         for (rdr_ctx::ShadowKey& k : c->cascades_key) k.valid = false;  // targets may be half written
         c->point_dynamic_key.valid = false;
         for (int age = RDR_FRAME_SLOTS - 1; age >= (c->frame_claimed ? 1 : 0); age--) harvest(c, (c->slot + RDR_FRAME_SLOTS - age) % RDR_FRAME_SLOTS);
