@@ -188,6 +188,31 @@ RDR_DEV void cube_sample(const DCube& cube, uint32_t level, float dx, float dy, 
     }
 }
 
+// cube_sample on a bordered copy of the cube (every face (r + 2)^2, the border holding the texels across the cube's
+// edges, k_cube_border): the footprint is four neighbouring words wherever it lies, the arithmetic is cube_sample's.
+RDR_DEV void cube_sample_bordered(const DCube& cube, uint32_t level, float dx, float dy, float dz, float out[3]) {
+    float s, t;
+    const int face = cube_face(dx, dy, dz, s, t);
+    const uint32_t rr = cube.res >> level;
+    const int r = (int)(rr ? rr : 1u), pitch = r + 2;
+    const RDR_GLOBAL uint32_t* px = as_global(cube.texels) + cube.level_offset[level];
+    const float tu = s * (float)r - 0.5f, tv = t * (float)r - 0.5f;
+    const float fu = floorf(tu), fv = floorf(tv);
+    const float a = tu - fu, b = tv - fv;
+    const int i0 = min(max((int)fu, -1), r - 1), j0 = min(max((int)fv, -1), r - 1);
+    const RDR_GLOBAL uint32_t* row = px + ((face * pitch + j0 + 1) * pitch + i0 + 1);
+    float c00[3], c10[3], c01[3], c11[3];
+    unpack_r11g11b10(row[0], c00[0], c00[1], c00[2]);
+    unpack_r11g11b10(row[1], c10[0], c10[1], c10[2]);
+    unpack_r11g11b10(row[pitch], c01[0], c01[1], c01[2]);
+    unpack_r11g11b10(row[pitch + 1], c11[0], c11[1], c11[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float top = (1.0f - a) * c00[k] + a * c10[k], bot = (1.0f - a) * c01[k] + a * c11[k];
+        out[k] = (1.0f - b) * top + b * bot;
+    }
+}
+
 // Products of two values below 2^23 (image sizes, rows, faces): the 24-bit multiplier issues at full rate, the 32-bit
 // one at a quarter of it.
 RDR_DEV int mul24(int a, int b) { return __mul24(a, b); }

@@ -39,6 +39,7 @@ RDR_DEV F3 bake_direction(int face, int x, int y, int res) {
 }
 
 // envbakediffuse.frag:12-40
+// `env` (both bakes): the bordered copy of the environment cube
 __global__ void __launch_bounds__(256) k_bake_irradiance(DCube env, uint32_t* __restrict__ dst, int res, IrradianceTables tb) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= 6u * res * res) return;
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256) k_bake_irradiance(DCube env, uint32_t* __
             const float tx = st * tb.cos_phi[a], ty = st * tb.sin_phi[a], tz = ct;
             const F3 sv = right * tx + up * ty + normal * tz;
             float e[3];
-            cube_sample(env, 0, sv.x, sv.y, sv.z, e);
+            cube_sample_bordered(env, 0, sv.x, sv.y, sv.z, e);
 #pragma unroll
             for (int k = 0; k < 3; k++) irr[k] += e[k] * ct * st;
         }
@@ -78,28 +79,36 @@ RDR_DEV float radical_inverse(uint32_t bits) {
 // envbakespecular.frag:32-86; cos/sin of phi_i = 2 pi i/128 come from `trig` (256 floats: cos then sin)
 __global__ void __launch_bounds__(256) k_bake_prefilter(DCube env, uint32_t* __restrict__ dst, int res, float roughness,
                                                         const float* __restrict__ trig) {
+    // The half vectors in tangent space depend on the sample and the level's roughness only: the block works them out
+    // once (the same operations in the same order as per texel before, so the same bits) instead of once per texel.
+    constexpr int nSamples = 128;
+    __shared__ float lds_h[3][nSamples];
+    if (threadIdx.x < (uint32_t)nSamples) {
+        const int s = (int)threadIdx.x;
+        const float a = roughness * roughness;
+        const float xi_y = radical_inverse((uint32_t)s);
+        const float cosTheta = sqrtf((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        lds_h[0][s] = trig[s] * sinTheta; lds_h[1][s] = trig[128 + s] * sinTheta; lds_h[2][s] = cosTheta;
+    }
+    __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= 6u * res * res) return;
     const int face = (int)(i / (uint32_t)(res * res)), y = (int)((i / (uint32_t)res) % (uint32_t)res), x = (int)(i % (uint32_t)res);
-    const int nSamples = 128;
     const F3 N = normalize3(bake_direction(face, x, y, res));
     const F3 V = N;
     float col[3] = {0.0f, 0.0f, 0.0f}, total = 0.0f;
-    const float a = roughness * roughness;
     const F3 upv = fabsf(N.z) < 0.999f ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
     const F3 tangent = normalize3(cross3(upv, N));
     const F3 bitangent = cross3(N, tangent);
     for (int s = 0; s < nSamples; s++) {
-        const float xi_y = radical_inverse((uint32_t)s);
-        const float cosTheta = sqrtf((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
-        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-        const float hx = trig[s] * sinTheta, hy = trig[128 + s] * sinTheta, hz = cosTheta;
+        const float hx = lds_h[0][s], hy = lds_h[1][s], hz = lds_h[2][s];
         const F3 H = normalize3(tangent * hx + bitangent * hy + N * hz);
         const F3 L = normalize3(H * (2.0f * dot3(V, H)) - V);
         const float NdotL = fmaxf(dot3(N, L), 0.0f);
         if (NdotL > 0.0f) {
             float e[3];
-            cube_sample(env, 0, L.x, L.y, L.z, e);
+            cube_sample_bordered(env, 0, L.x, L.y, L.z, e);
 #pragma unroll
             for (int k = 0; k < 3; k++) col[k] += e[k] * NdotL;
             total += NdotL;

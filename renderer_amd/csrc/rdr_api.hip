@@ -1617,6 +1617,15 @@ struct StreamTimer {
 static int bake_environment(rdr_ctx* c, uint32_t w) {
     memset(&c->env, 0, sizeof c->env);
     c->env.texels = c->d_env.as<uint32_t>(); c->env.res = w; c->env.levels = 1;
+    // the bordered copy first: the bakes read it too (four neighbouring texels per tap instead of folding the footprint
+    // over the cube's edges tap by tap: the same texels, the same sums)
+    {
+        c->env_b = c->env;
+        c->env_b.level_offset[0] = 0;
+        HIP_TRY(c->d_env_b.ensure((size_t)6 * (w + 2) * (w + 2) * 4 + 16));  // the shading kernels read texel pairs: one texel of slack
+        launch_cube_border(c->stream, c->env.texels, c->d_env_b.as<uint32_t>(), (int)w);
+        c->env_b.texels = c->d_env_b.as<uint32_t>();
+    }
     // irradiance: 256^2 per face (VulkanRenderer.h:220)
     {
         const int res = 256;
@@ -1628,7 +1637,7 @@ static int bake_environment(rdr_ctx* c, uint32_t w) {
         for (int i = 0; i < 24; i++) { const float phi = i * stepRads; tb.cos_phi[i] = cosf(phi); tb.sin_phi[i] = sinf(phi); }
         for (int j = 0; j < 6; j++) { const float theta = j * stepRads; tb.sin_theta[j] = sinf(theta); tb.cos_theta[j] = cosf(theta); }
         StreamTimer t(c->stream);
-        launch_bake_irradiance(c->stream, c->env, c->d_irradiance.as<uint32_t>(), res, tb);
+        launch_bake_irradiance(c->stream, c->env_b, c->d_irradiance.as<uint32_t>(), res, tb);
         c->precompute_ms[1] = t.stop();
         memset(&c->irradiance, 0, sizeof c->irradiance);
         c->irradiance.texels = c->d_irradiance.as<uint32_t>(); c->irradiance.res = res; c->irradiance.levels = 1;
@@ -1652,7 +1661,7 @@ static int bake_environment(rdr_ctx* c, uint32_t w) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         StreamTimer t(c->stream);
         for (int l = 0; l < levels; l++)
-            launch_bake_prefilter(c->stream, c->env, c->d_prefiltered.as<uint32_t>() + c->prefiltered.level_offset[l], base >> l, (float)l / 9,
+            launch_bake_prefilter(c->stream, c->env_b, c->d_prefiltered.as<uint32_t>() + c->prefiltered.level_offset[l], base >> l, (float)l / 9,
                                   c->d_trig.as<float>());
         c->precompute_ms[2] = t.stop();
         c->prefiltered.texels = c->d_prefiltered.as<uint32_t>(); c->prefiltered.res = base; c->prefiltered.levels = levels;
@@ -1672,7 +1681,6 @@ static int bake_environment(rdr_ctx* c, uint32_t w) {
         dst.texels = buf.as<uint32_t>();
         return RDR_OK;
     };
-    RDR_TRY(add_border(c->env, c->d_env_b, c->env_b));
     RDR_TRY(add_border(c->irradiance, c->d_irradiance_b, c->irradiance_b));
     RDR_TRY(add_border(c->prefiltered, c->d_prefiltered_b, c->prefiltered_b));
     auto add_quads = [&](const DCube& bordered, DevBuf& buf, DCube& dst) -> int {
