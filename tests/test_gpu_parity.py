@@ -299,3 +299,29 @@ def test_fragment_lists_from_the_rasteriser_or_from_the_visibility_image(hip_cap
         for x, y, what in zip(a[:4], b[:4], ("frame", "hdr", "depth", "visibility")):
             assert np.array_equal(x, y), f"{what} of frame {k} differs between the two ways of building the lists"
         assert a[4] == b[4]
+
+
+def test_pair_scan_and_sort_in_one_launch_or_in_several(hip_capi, monkeypatch):
+    """Below two million elements the pair-count scan is one chained kernel and a digit pass of the pair sort is one
+    chained kernel; above, and with RDR_SCAN_CLASSIC=1 / RDR_SORT_CLASSIC=1, they are the multi-kernel versions. The
+    tile lists they produce must be the same, so depth, visibility, the shadow maps and the frame are equal bit for
+    bit, over several frames on one context (the chained kernels leave their status words for the next launch)."""
+    from renderer_amd.api import Renderer
+    frames = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RDR_SCAN_CLASSIC", mode)
+        monkeypatch.setenv("RDR_SORT_CLASSIC", mode)
+        r = Renderer(hip_capi, 333, 207, hp.default_settings(**hp.small_settings(4)))
+        scenes.small_scene(r)
+        got = []
+        for k in range(3):
+            r.set_camera(position=(0.3 * k - 0.4, 1.3, 4.0 - 0.3 * k), euler=(-0.12, 0.07 * k, 0.0))
+            out, avg = r.render_frame(exposure_mode=1, temporal_luminance=0.5)
+            got.append((out.copy(), r.read_hdr(), r.read_depth(), r.read_visibility(), r.read_directional_shadow(0), avg))
+        frames[mode] = got
+        r.close()
+    for k in range(3):
+        a, b = frames["0"][k], frames["1"][k]
+        for x, y, what in zip(a[:5], b[:5], ("frame", "hdr", "depth", "visibility", "cascade 0")):
+            assert np.array_equal(x, y), f"{what} of frame {k} differs between the chained and the multi-kernel scan / sort"
+        assert a[5] == b[5]
