@@ -9,8 +9,8 @@ occluders and a moving one - so that pbr.frag:136-155 (the cube-shadow reference
 normalised L) has known answers too.
 
 What the answer takes from the library under test, read back through the C ABI, is only what other known-answer tests
-pin on their own: the packed environment cubes (bake tests in test_shading_kat.py), the cascade matrices and the depth
-maps of cascades and cube faces (coverage / depth tests in test_oracle_kat.py; where the cube faces put their shadows is
+pin on their own: the packed environment cubes (bake tests in test_shading_kat.py), the cascade matrices
+(test_cascade_kat.py) and the depth maps of cascades and cube faces (coverage / depth tests in test_oracle_kat.py; where the cube faces put their shadows is
 checked against the scene's geometry in test_shading_kat.py), and the mip levels of the images (checked there against
 the float64 blit before they are used).
 """
