@@ -573,18 +573,44 @@ RDR_DEV uint32_t find_draw_by_tri(const uint32_t* __restrict__ first_tri, uint32
 // `pair_offset` is the rasteriser's exclusive scan of (triangle, tile) pair counts, starting at this view's first
 // triangle and running on for `n_after` instances, with the grand total in *pair_total: a triangle that owns no
 // pair (clipped away, culled, degenerate) can never be visible and is skipped.
+// The 384-byte records leave through LDS: a lane that stored its own record would send it out as 24 separate 16-byte
+// pieces, 384 bytes apart from its neighbours', and the memory system sees 2.4 GB of partial-line writes for 0.8 GB of
+// records (ten-million-triangle grid). Half a wave's records are parked at a time, then the whole wave writes them
+// out with neighbouring lanes on neighbouring 16-byte pieces: whole lines.
+struct alignas(16) ShadeTriSlot { DShadeTri t; uint32_t spread[4]; };  // 400 bytes apart: the lanes' parking stores spread over the banks
 __global__ void __launch_bounds__(256) k_shade_setup(const DFrame* __restrict__ frp, const DDraw* __restrict__ draws,
                                                      const uint32_t* __restrict__ first_tri, uint32_t n_draws, uint32_t n_tris,
                                                      const uint32_t* __restrict__ pair_offset, uint32_t n_after,
                                                      const uint32_t* __restrict__ pair_total, DShadeTri* __restrict__ out) {
+    __shared__ ShadeTriSlot lds_slot[256 / 64][32];
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= n_tris) return;
-    if ((id + 1u < n_after ? pair_offset[id + 1u] : pair_total[0]) == pair_offset[id]) return;
-    const uint32_t di = find_draw_by_tri(first_tri, n_draws, id);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const bool alive = id < n_tris && (id + 1u < n_after ? pair_offset[id + 1u] : pair_total[0]) != pair_offset[id];
+    const unsigned long long live = __ballot(alive);
+    if (!live) return;  // uniform
     DShadeTri t;
-    shade_tri_setup(*frp, draws[di], id - first_tri[di], t);
-    t._pad[0] = t._pad[1] = t._pad[2] = 0u;
-    out[id] = t;
+    if (alive) {
+        const uint32_t di = find_draw_by_tri(first_tri, n_draws, id);
+        shade_tri_setup(*frp, draws[di], id - first_tri[di], t);
+        t._pad[0] = t._pad[1] = t._pad[2] = 0u;
+    }
+    const uint32_t wave_id0 = id - lane;  // the wave's 64 triangles are consecutive
+#pragma unroll
+    for (uint32_t half = 0; half < 2u; half++) {
+        const unsigned long long part = (live >> (32u * half)) & 0xFFFFFFFFull;
+        if (!part) continue;  // uniform
+        if (alive && (lane >> 5) == half) lds_slot[wave][lane & 31u].t = t;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a wave's LDS accesses run in order: its own stores are there
+        // 32 records x 24 pieces of 16 bytes, 64 pieces per turn
+        for (uint32_t f = lane; f < 32u * RDR_SHADE_TRI_VEC4; f += 64u) {
+            const uint32_t r = f / RDR_SHADE_TRI_VEC4, piece = f % RDR_SHADE_TRI_VEC4;
+            if ((part >> r) & 1ull) {
+                const rdr_uint4_t q = ((const rdr_uint4_t*)&lds_slot[wave][r].t)[piece];
+                ((rdr_uint4_t*)(out + (wave_id0 + 32u * half + r)))[piece] = q;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the other half parks its records
+    }
 }
 
 #define SHADE_NO_FRAGMENT 0xFFu
