@@ -301,7 +301,8 @@ def test_fragment_lists_from_the_rasteriser_or_from_the_visibility_image(hip_cap
         assert a[4] == b[4]
 
 
-def test_pair_scan_and_sort_in_one_launch_or_in_several(hip_capi, monkeypatch):
+@pytest.mark.parametrize("big_maps", [False, True])
+def test_pair_scan_and_sort_in_one_launch_or_in_several(hip_capi, monkeypatch, big_maps):
     """Below two million elements the pair-count scan is one chained kernel and a digit pass of the pair sort is one
     chained kernel; above, and with RDR_SCAN_CLASSIC=1 / RDR_SORT_CLASSIC=1, they are the multi-kernel versions. The
     tile lists they produce must be the same, so depth, visibility, the shadow maps and the frame are equal bit for
@@ -311,17 +312,23 @@ def test_pair_scan_and_sort_in_one_launch_or_in_several(hip_capi, monkeypatch):
     for mode in ("0", "1"):
         monkeypatch.setenv("RDR_SCAN_CLASSIC", mode)
         monkeypatch.setenv("RDR_SORT_CLASSIC", mode)
-        r = Renderer(hip_capi, 333, 207, hp.default_settings(**hp.small_settings(4)))
+        # big_maps: 2048^2 cascades and eight 1024^2 cubes make more than 2^18 tiles, i.e. three digits of seven bits
+        # instead of two of nine
+        settings = dict(hp.small_settings(4))
+        if big_maps:
+            settings.update(directional_shadow_map_resolution=2048, point_shadow_map_resolution=1024, point_shadow_map_count=8)
+        r = Renderer(hip_capi, 333, 207, hp.default_settings(**settings))
         scenes.small_scene(r)
         got = []
         for k in range(3):
             r.set_camera(position=(0.3 * k - 0.4, 1.3, 4.0 - 0.3 * k), euler=(-0.12, 0.07 * k, 0.0))
             out, avg = r.render_frame(exposure_mode=1, temporal_luminance=0.5)
-            got.append((out.copy(), r.read_hdr(), r.read_depth(), r.read_visibility(), r.read_directional_shadow(0), avg))
+            got.append((out.copy(), r.read_hdr(), r.read_depth(), r.read_visibility(), r.read_directional_shadow(0), avg,
+                        r.read_point_shadow(1, 3)))
         frames[mode] = got
         r.close()
     for k in range(3):
         a, b = frames["0"][k], frames["1"][k]
-        for x, y, what in zip(a[:5], b[:5], ("frame", "hdr", "depth", "visibility", "cascade 0")):
+        for x, y, what in zip(a[:5] + a[6:], b[:5] + b[6:], ("frame", "hdr", "depth", "visibility", "cascade 0", "cube 1 face -Y")):
             assert np.array_equal(x, y), f"{what} of frame {k} differs between the chained and the multi-kernel scan / sort"
         assert a[5] == b[5]
