@@ -358,8 +358,11 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
             tex_resolve<7>(srgb, td[1], taps0, r1, t);
             nmap[0] = t[0]; nmap[1] = t[1]; nmap[2] = t[2];
             RDR_TEX_FENCE();
+            // glTF files usually pack occlusion, roughness and metalness into one image (main.cpp:135-166 reads the two
+            // slots independently): when every fragment of the wave has the same image in both slots, it is fetched once
+            const bool shared_orm = __all(td[3].base == td[2].base) != 0;
             if (RDR_TEX_SERIAL) tex_issue(td[0], taps0, r0);
-            else { tex_issue(td[3], taps0, r3); if (any_emissive) tex_issue(td[4], taps0, r4); }
+            else { if (!shared_orm) tex_issue(td[3], taps0, r3); if (any_emissive) tex_issue(td[4], taps0, r4); }
             tex_resolve<15>(srgb, td[0], taps0, r0, t);
 #pragma unroll
             for (int k = 0; k < 4; k++) albedo[k] = t[k] * mt.base_color[k];
@@ -370,8 +373,9 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
             metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
             roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
             RDR_TEX_FENCE();
-            if (RDR_TEX_SERIAL) tex_issue(td[3], taps0, r3);
-            tex_resolve<1>(srgb, td[3], taps0, r3, t);
+            if (RDR_TEX_SERIAL && !shared_orm) tex_issue(td[3], taps0, r3);
+            if (shared_orm) tex_resolve<1>(srgb, td[3], taps0, r2, t);  // same geometry (this branch), same texels
+            else tex_resolve<1>(srgb, td[3], taps0, r3, t);
             ao = t[0] * mt.ao;
             if (any_emissive) {
                 RDR_TEX_FENCE();

@@ -332,3 +332,29 @@ def test_pair_scan_and_sort_in_one_launch_or_in_several(hip_capi, monkeypatch, b
         for x, y, what in zip(a[:5] + a[6:], b[:5] + b[6:], ("frame", "hdr", "depth", "visibility", "cascade 0", "cube 1 face -Y")):
             assert np.array_equal(x, y), f"{what} of frame {k} differs between the chained and the multi-kernel scan / sort"
         assert a[5] == b[5]
+
+
+def test_occlusion_and_metal_roughness_in_one_image(orc_capi, hip_capi, monkeypatch):
+    """glTF assets usually pack occlusion (R), roughness (G) and metalness (B) into one image and name it in both
+    material slots (main.cpp:135-166 reads the slots independently). The shading kernel then fetches the image once
+    per fragment; the frame must equal the checker's, which samples both slots, as closely as with five images."""
+    textures = scenes.material_textures
+
+    def packed(r, size, seed, **kw):
+        t = list(textures(r, size, seed, **kw))
+        t[2] = t[3]  # the grey occlusion image in both slots: occlusion from R, roughness from G, metalness from B, none of them 0
+        return t
+
+    monkeypatch.setattr(scenes, "material_textures", packed)
+    W, H = 320, 180
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, **hp.small_settings(4))
+    scenes.small_scene(ro)
+    scenes.small_scene(rh)
+    out_o, avg_o = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    out_h, avg_h = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    assert np.array_equal(ro.read_visibility(), rh.read_visibility())
+    hp.assert_image_close(out_o, out_h)
+    assert avg_o == avg_h or abs(avg_o - avg_h) < 1e-3
+    hdr_o, hdr_h = ro.read_hdr(), rh.read_hdr()
+    # the colour image to half precision nearly everywhere (a shadow edge may fall on the other side of a sample in a few pixels)
+    assert np.mean(np.abs(hdr_o - hdr_h) > 4e-3 * np.abs(hdr_o) + 2e-3) < 1e-3
