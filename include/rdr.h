@@ -76,7 +76,8 @@ typedef struct rdr_sampler {
     uint32_t min_filter;
     uint32_t mipmap_filter;
     uint32_t wrap_u;
-    uint32_t wrap_v;
+    uint32_t wrap_v;   /* as the reference reads it (VulkanRenderer.cpp:370-371): REPEAT if it says REPEAT; otherwise
+                        * MIRROR when wrap_u is MIRROR and CLAMP when it is not, whatever wrap_v itself names */
 } rdr_sampler;
 
 /* Vertex attribute / index descriptions: Renderer/Mesh.h:12-80. */

@@ -359,7 +359,12 @@ int orc_make_texture(rdr_ctx* c, uint32_t image, const rdr_sampler* s, uint32_t*
     if (s->mag_filter != RDR_FILTER_LINEAR || s->min_filter != RDR_FILTER_LINEAR || s->mipmap_filter != RDR_FILTER_LINEAR)
         return fail(c, RDR_ERR_UNSUPPORTED, "make_texture: only LINEAR filters are supported");
     if (s->wrap_u > RDR_WRAP_CLAMP || s->wrap_v > RDR_WRAP_CLAMP) return fail(c, RDR_ERR_INVALID, "make_texture: bad wrap mode");
-    c->textures.push_back(Texture{image, *s});
+    // VulkanRenderer.cpp:370-371: the V address mode is REPEAT if wrapV says so; otherwise it is chosen by wrapU (the
+    // reference tests wrapU for "mirror" in both lines), so (REPEAT, MIRROR) samples V clamped and (MIRROR, CLAMP)
+    // samples V mirrored. Kept: it is what the reference's sampler does.
+    rdr_sampler eff = *s;
+    if (eff.wrap_v != RDR_WRAP_REPEAT) eff.wrap_v = eff.wrap_u == RDR_WRAP_MIRROR ? RDR_WRAP_MIRROR : RDR_WRAP_CLAMP;
+    c->textures.push_back(Texture{image, eff});
     *out_id = (uint32_t)c->textures.size() - 1;
     return RDR_OK;
 }

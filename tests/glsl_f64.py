@@ -225,15 +225,38 @@ def wrap_repeat(i, n):
     return np.mod(i, n)
 
 
-def bilinear_repeat(level, u, v):
-    """LINEAR filter with REPEAT addressing on one level [h, w, C] of already decoded float texels."""
+REPEAT, MIRRORED_REPEAT, CLAMP_TO_EDGE = 0, 1, 2
+
+
+def wrap_texel(i, n, mode):
+    """Vulkan 1.3 "Wrapping Operation" on an integer texel coordinate: REPEAT i mod n; MIRRORED_REPEAT
+    (n - 1) - mirror((i mod 2n) - n) with mirror(k) = k if k >= 0 else -(1 + k); CLAMP_TO_EDGE clamp(i, 0, n - 1)."""
+    if mode == REPEAT:
+        return np.mod(i, n)
+    if mode == MIRRORED_REPEAT:
+        k = np.mod(i, 2 * n) - n
+        return (n - 1) - np.where(k >= 0, k, -(1 + k))
+    return np.clip(i, 0, n - 1)
+
+
+def reference_address_modes(wrap_u, wrap_v):
+    """The address modes VulkanRenderer.cpp:370-371 builds from a Sampler's wrapU / wrapV: U as named; V REPEAT if wrapV
+    says REPEAT, otherwise MIRRORED_REPEAT if *wrapU* is the mirror mode and CLAMP_TO_EDGE if it is not (the second
+    line of the reference tests wrapU where one would expect wrapV)."""
+    return wrap_u, (REPEAT if wrap_v == REPEAT else (MIRRORED_REPEAT if wrap_u == MIRRORED_REPEAT else CLAMP_TO_EDGE))
+
+
+def bilinear_repeat(level, u, v, modes=(REPEAT, REPEAT)):
+    """LINEAR filter on one level [h, w, C] of already decoded float texels with the address modes `modes` = (U, V)."""
     h, w = level.shape[:2]
     x, y = u * w - 0.5, v * h - 0.5
     i0, j0 = np.floor(x), np.floor(y)
     a, b = (x - i0)[..., None], (y - j0)[..., None]
     i0, j0 = i0.astype(np.int64), j0.astype(np.int64)
-    c00, c10 = level[wrap_repeat(j0, h), wrap_repeat(i0, w)], level[wrap_repeat(j0, h), wrap_repeat(i0 + 1, w)]
-    c01, c11 = level[wrap_repeat(j0 + 1, h), wrap_repeat(i0, w)], level[wrap_repeat(j0 + 1, h), wrap_repeat(i0 + 1, w)]
+    iu0, iu1 = wrap_texel(i0, w, modes[0]), wrap_texel(i0 + 1, w, modes[0])
+    jv0, jv1 = wrap_texel(j0, h, modes[1]), wrap_texel(j0 + 1, h, modes[1])
+    c00, c10 = level[jv0, iu0], level[jv0, iu1]
+    c01, c11 = level[jv1, iu0], level[jv1, iu1]
     return (1 - b) * ((1 - a) * c00 + a * c10) + b * ((1 - a) * c01 + a * c11)
 
 
@@ -257,10 +280,10 @@ def texture_lod(levels, dudx, dvdx, dudy, dvdy):
     return np.clip(lam, 0.0, len(levels) - 1.0)
 
 
-def texture_2d(levels, u, v, dudx, dvdx, dudy, dvdy):
-    """texture(sampler2D, uv) with mag/min LINEAR, mipmap mode LINEAR, REPEAT (VulkanRenderer.cpp:41): the two levels
-    around lambda, each filtered bilinearly, blended by the fraction. `levels`: decoded float texels per mip level.
-    Returns (value [n, C], lambda [n])."""
+def texture_2d(levels, u, v, dudx, dvdx, dudy, dvdy, modes=(REPEAT, REPEAT)):
+    """texture(sampler2D, uv) with mag/min LINEAR, mipmap mode LINEAR (VulkanRenderer.cpp:363-385) and the address modes
+    `modes`: the two levels around lambda, each filtered bilinearly, blended by the fraction. `levels`: decoded float
+    texels per mip level. Returns (value [n, C], lambda [n])."""
     lam = texture_lod(levels, dudx, dvdx, dudy, dvdy)
     l0 = np.floor(lam).astype(np.int64)
     l1 = np.minimum(l0 + 1, len(levels) - 1)
@@ -270,7 +293,7 @@ def texture_2d(levels, u, v, dudx, dvdx, dudy, dvdy):
         m0, m1 = l0 == lv, l1 == lv
         if not (m0.any() or m1.any()):
             continue
-        val = bilinear_repeat(levels[lv], u, v)
+        val = bilinear_repeat(levels[lv], u, v, modes)
         out = out + np.where(m0[..., None], (1 - f) * val, 0.0) + np.where(m1[..., None], f * val, 0.0)
     return out, lam
 
@@ -375,7 +398,7 @@ def material_samples(frag, mat):
         if mat.get("chains"):
             levels = [decode_texels(lv, srgb) for lv in mat["chains"][name]]
             out[name], _ = texture_2d(levels, frag["uv"][:, 0], frag["uv"][:, 1], frag["duvdx"][:, 0], frag["duvdx"][:, 1],
-                                      frag["duvdy"][:, 0], frag["duvdy"][:, 1])
+                                      frag["duvdy"][:, 0], frag["duvdy"][:, 1], reference_address_modes(*mat.get("wrap", (REPEAT, REPEAT))))
         else:
             out[name] = np.broadcast_to(decode_texels(np.asarray(mat[name], np.uint8), srgb), (n, 4))
     return out

@@ -97,9 +97,10 @@ def _chain_images(size, seed, crop=None, **kw):
 def detail_prims():
     """Opaque primitives, then MASK / BLEND ones, of the "detail" variant. `images` holds level 0 of the five textures;
     the chains are read back from the renderer (build() stores the image ids)."""
-    def mat(images, **kw):
+    def mat(images, wrap=(B.WRAP_REPEAT, B.WRAP_REPEAT), **kw):
         m = _mat((0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), **kw)
         m["images"] = images
+        m["wrap"] = wrap   # the Sampler's wrapU / wrapV as handed to makeTexture
         return m
     ground = KatPrim(scenes.plane(30, 30, 1, 1, uv_scale=24.0), scenes.translation(0, 0, -12) @ G.rotate(0.1, 2) @ SCALE,
                      mat(_chain_images(128, 501, tint=(0.9, 0.8, 0.7)), base_color=(0.9, 0.8, 0.7, 1.0), emissive=(0.5, 0.25, 0.125),
@@ -107,7 +108,8 @@ def detail_prims():
     box = KatPrim(scenes.box(1.5, 1.0, 1.5, 1, uv_scale=0.3), scenes.translation(0.5, 2.0, -3.0) @ G.rotate(0.4, 1),
                   mat(_chain_images(64, 511, tint=(0.6, 0.9, 0.7), metal_fraction=0.6), metallic=1.0, roughness=0.7))
     wall = KatPrim(scenes.plane(3, 2, 1, 1, uv_scale=3.0), scenes.translation(-3.0, 1.6, -2.5) @ G.rotate(np.pi / 2 - 0.2, 0) @ G.rotate(0.3, 2),
-                   mat(_chain_images(128, 521, crop=(96, 40), tint=(0.5, 0.7, 1.0)), base_color=(0.6, 0.8, 0.9, 1.0), metallic=0.35, roughness=0.5))
+                   mat(_chain_images(128, 521, crop=(96, 40), tint=(0.5, 0.7, 1.0)), base_color=(0.6, 0.8, 0.9, 1.0), metallic=0.35, roughness=0.5,
+                       wrap=(B.WRAP_MIRROR, B.WRAP_CLAMP)))   # uv runs to 3: U mirrored; V mirrored too, by VulkanRenderer.cpp:371
     # the moving box mixes image sizes inside one material (normal and metal-rough maps of 32^2 beside 64^2 ones)
     mixed = dict(_chain_images(64, 531, tint=(1.0, 0.6, 0.5)))
     small = _chain_images(32, 551)
@@ -116,7 +118,8 @@ def detail_prims():
                     mat(mixed, metallic=0.2, roughness=0.6), dynamic=True)
     alpha = scenes.value_noise(64, 77, octaves=2, base=4)
     card = KatPrim(scenes.plane(1.6, 1.6, 1, 1, uv_scale=1.5), scenes.translation(3.0, 1.2, -1.0) @ G.rotate(np.pi / 2, 0),
-                   mat(_chain_images(64, 541, tint=(0.5, 1.0, 0.5), alpha=(0.2 + 0.6 * alpha).astype(np.float32)), alpha_mode=B.ALPHA_MASK, alpha_cutoff=0.5))
+                   mat(_chain_images(64, 541, tint=(0.5, 1.0, 0.5), alpha=(0.2 + 0.6 * alpha).astype(np.float32)), alpha_mode=B.ALPHA_MASK, alpha_cutoff=0.5,
+                       wrap=(B.WRAP_CLAMP, B.WRAP_MIRROR)))   # uv runs to 1.5: U clamped; V clamped too (wrapU is not the mirror mode)
     return [ground, box, wall, mover], [card]
 
 
@@ -158,7 +161,7 @@ def build(r, env_faces, lut=None, with_meshes=True, variant="base"):
             m = p.mat
             if "images" in m:
                 m["image_ids"] = [r.load_image(m["images"][name], f) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
-                tex = [r.make_texture(i) for i in m["image_ids"]]
+                tex = [r.make_texture(i, *m["wrap"]) for i in m["image_ids"]]
             else:
                 tex = [r.make_texture(r.load_image(np.asarray(m[name], np.uint8).reshape(1, 1, 4), f)) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
             material = scenes.make_material(tex, base_color=m["base_color"], emissive=m["emissive"], metallic=m["metallic"],
