@@ -42,7 +42,9 @@ typedef struct rdr_ctx rdr_ctx;
 /* Mirrors RendererSettings (Renderer/VulkanRenderer.h:44-59) field for field;
  * bools widened to uint32_t so the struct has no padding surprises. */
 typedef struct rdr_settings {
-    uint32_t hdr_output_enabled;               /* must be 0: the output is 8-bit UNORM; rdr_create refuses 1 with RDR_ERR_UNSUPPORTED */
+    uint32_t hdr_output_enabled;               /* default 0: the output image is R8G8B8A8_UNORM. 1: R16G16B16A16_SFLOAT (the float
+                                                * format of VulkanRenderer.cpp:668-673 that presentation surfaces offer; there is no
+                                                * surface to ask here): tonemap.comp's values unquantised, 8 bytes per pixel */
     uint32_t dynamic_shadows_enabled;          /* default 1   */
     uint32_t point_shadow_map_resolution;      /* default 512;  1 .. 8192  */
     uint32_t point_shadow_map_count;           /* default 8;    0 .. 64    */
@@ -72,9 +74,9 @@ enum rdr_image_format {
 enum rdr_sampler_filter { RDR_FILTER_NEAREST = 0, RDR_FILTER_LINEAR = 1 };
 enum rdr_sampler_wrap { RDR_WRAP_REPEAT = 0, RDR_WRAP_MIRROR = 1, RDR_WRAP_CLAMP = 2 };
 typedef struct rdr_sampler {
-    uint32_t mag_filter;
-    uint32_t min_filter;
-    uint32_t mipmap_filter;
+    uint32_t mag_filter;     /* within a level where the level of detail lambda <= 0 */
+    uint32_t min_filter;     /* within a level where lambda > 0 */
+    uint32_t mipmap_filter;  /* LINEAR: the two levels around lambda blended; NEAREST: level ceil(lambda + 0.5) - 1 */
     uint32_t wrap_u;
     uint32_t wrap_v;   /* as the reference reads it (VulkanRenderer.cpp:370-371): REPEAT if it says REPEAT; otherwise
                         * MIRROR when wrap_u is MIRROR and CLAMP when it is not, whatever wrap_v itself names */
@@ -309,7 +311,10 @@ int rdr_set_exposure_bias(rdr_ctx* ctx, float exposure_bias, float gamma);
 
 /* One iteration of VulkanRenderer::renderLoop (VulkanRenderer.cpp:1013-1110):
  * shadow maps -> main pass (opaque, skybox, blended) -> bloom -> tonemap ->
- * average luminance. `out_rgba8` receives width*height*4 bytes, row 0 first;
+ * average luminance. `out_rgba8` receives width*height*4 bytes, row 0 first
+ * (width*height*8 bytes of RGBA16F when the context was created with
+ * hdr_output_enabled; the same holds for the out_rgba8 of rdr_post_process
+ * and rdr_post_process_noalloc, whose destination must then be 16-byte aligned);
  * it is a host pointer, or a device pointer when out_is_device != 0 (then the
  * call only enqueues work on the context's stream; use rdr_synchronize).
  * NULL skips the copy.

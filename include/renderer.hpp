@@ -481,7 +481,8 @@ struct FrameParams {
 // ---- the renderer (public surface of VulkanRenderer, VulkanRenderer.h:94-110) -----------
 class Renderer {
 public:
-    Renderer(uint32_t width, uint32_t height, const RendererSettings& s, int device = 0) : _settings(s), _width(width), _height(height) {
+    Renderer(uint32_t width, uint32_t height, const RendererSettings& s, int device = 0)
+        : _settings(s), _width(width), _height(height), hdrOutput(s.hdrOutputEnabled) {
         rdr_settings a;
         a.hdr_output_enabled = s.hdrOutputEnabled; a.dynamic_shadows_enabled = s.dynamicShadowsEnabled;
         a.point_shadow_map_resolution = s.pointShadowMapResolution; a.point_shadow_map_count = s.pointShadowMapCount;
@@ -628,9 +629,11 @@ public:
     uint32_t height() const { return _height; }
 
     // One iteration of renderLoop (VulkanRenderer.cpp:1013-1110): reads every mesh's node->modelMatrix() (:975), the
-    // camera and the two settings the loop re-reads each frame, renders, returns width*height*4 bytes.
+    // camera and the two settings the loop re-reads each frame, renders, returns width*height*4 bytes (RGBA8), or with
+    // hdrOutputEnabled width*height*8 bytes (RGBA16F).
+    size_t outputPixelBytes() const { return hdrOutput ? 8u : 4u; }
     std::vector<uint8_t> renderFrame(const FrameParams& fp, float* avgLogLuminance = nullptr) {
-        std::vector<uint8_t> out((size_t)_width * _height * 4);
+        std::vector<uint8_t> out((size_t)_width * _height * outputPixelBytes());
         renderFrameInto(fp, out.data(), false, avgLogLuminance);
         return out;
     }
@@ -671,6 +674,7 @@ private:
     RendererSettings _settings;
     Camera _camera;
     uint32_t _width, _height;
+    bool hdrOutput;  // fixed at creation: settings().hdrOutputEnabled is not re-read (the swap chain is not rebuilt either)
     std::vector<Node*> rootNodes;
     std::vector<MeshSlot> meshes;
     std::atomic<bool> running{false};

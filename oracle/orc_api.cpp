@@ -294,9 +294,9 @@ int orc_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     if (!settings || !out || width == 0 || height == 0) return RDR_ERR_INVALID;
     if ((settings->msaa != 1 && settings->msaa != 4) || settings->directional_shadow_cascade_levels < 1 || settings->directional_shadow_cascade_levels > 4)
         return RDR_ERR_UNSUPPORTED;
-    // what the implementation does not offer is refused, not ignored: an HDR output image (VulkanRenderer.h:45), shadow
-    // maps whose tile boxes would not fit 16-bit coordinates, more cube slots than a frame can reasonably hold
-    if (settings->hdr_output_enabled) return RDR_ERR_UNSUPPORTED;
+    // what the implementation does not offer is refused, not ignored: shadow maps whose tile boxes would not fit 16-bit
+    // coordinates, more cube slots than a frame can reasonably hold
+    if (settings->hdr_output_enabled > 1) return RDR_ERR_INVALID;
     if (settings->directional_shadow_map_resolution == 0 || settings->point_shadow_map_resolution == 0) return RDR_ERR_INVALID;
     if (settings->directional_shadow_map_resolution > 16384 || settings->point_shadow_map_resolution > 8192 || settings->point_shadow_map_count > 64)
         return RDR_ERR_UNSUPPORTED;
@@ -356,8 +356,8 @@ int orc_load_image(rdr_ctx* c, const void* ptr, size_t size, uint32_t w, uint32_
 
 int orc_make_texture(rdr_ctx* c, uint32_t image, const rdr_sampler* s, uint32_t* out_id) {
     if (!c || !s || !out_id || image >= c->images.size()) return fail(c, RDR_ERR_INVALID, "make_texture: bad argument");
-    if (s->mag_filter != RDR_FILTER_LINEAR || s->min_filter != RDR_FILTER_LINEAR || s->mipmap_filter != RDR_FILTER_LINEAR)
-        return fail(c, RDR_ERR_UNSUPPORTED, "make_texture: only LINEAR filters are supported");
+    if (s->mag_filter > RDR_FILTER_LINEAR || s->min_filter > RDR_FILTER_LINEAR || s->mipmap_filter > RDR_FILTER_LINEAR)
+        return fail(c, RDR_ERR_INVALID, "make_texture: bad filter");
     if (s->wrap_u > RDR_WRAP_CLAMP || s->wrap_v > RDR_WRAP_CLAMP) return fail(c, RDR_ERR_INVALID, "make_texture: bad wrap mode");
     // VulkanRenderer.cpp:370-371: the V address mode is REPEAT if wrapV says so; otherwise it is chosen by wrapU (the
     // reference tests wrapU for "mirror" in both lines), so (REPEAT, MIRROR) samples V clamped and (MIRROR, CLAMP)

@@ -2,6 +2,7 @@
 // Bloom chain, tonemap and average luminance.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "orc_types.h"
 
@@ -90,12 +91,16 @@ static inline float tone(float x) {
 }
 
 // Renderer/shaders/tonemap.comp:34-53, pushed {exposure, gamma}
-// (Renderer/VulkanRenderer.cpp:1094). The output image is the swapchain image,
-// R8G8B8A8_UNORM in the SDR path (VulkanRenderer.cpp:673-676).
+// (Renderer/VulkanRenderer.cpp:1094). The output image is the swapchain image:
+// R8G8B8A8_UNORM in the SDR path (VulkanRenderer.cpp:673-676); with hdrOutputEnabled
+// a float format (VulkanRenderer.cpp:668-673), here R16G16B16A16_SFLOAT, the one of the
+// three that presentation surfaces offer: the same values, stored as binary16 (4 x 2 bytes
+// per pixel, alpha 1.0 as tonemap.comp:52 writes it).
 static void tonemap(Ctx& c, float exposure) {
     const uint32_t W = c.W, H = c.H;
     const float gamma = c.settings.gamma;
-    c.out.assign((size_t)W * H * 4, 0);
+    const bool hdr_out = c.settings.hdr_output_enabled != 0;
+    c.out.assign((size_t)W * H * (hdr_out ? 8 : 4), 0);
     c.loglum.assign((size_t)W * H, 0.0f);
     const float white = tone(11.2f);
     const float scale = std::pow(2.0f, exposure);
@@ -113,9 +118,11 @@ static void tonemap(Ctx& c, float exposure) {
             v = tone(v) / white;
             v = 1.0f - std::exp(-v * scale);
             v = std::pow(v, inv_gamma);
-            c.out[(size_t)i * 4 + k] = float_to_unorm8(v);
+            if (hdr_out) { const uint16_t h = float_to_half(v); std::memcpy(&c.out[(size_t)i * 8 + 2 * k], &h, 2); }
+            else c.out[(size_t)i * 4 + k] = float_to_unorm8(v);
         }
-        c.out[(size_t)i * 4 + 3] = 255;
+        if (hdr_out) { const uint16_t one = 0x3C00; std::memcpy(&c.out[(size_t)i * 8 + 6], &one, 2); }
+        else c.out[(size_t)i * 4 + 3] = 255;
     }
 }
 

@@ -84,24 +84,46 @@ static void bilinear(const Ctx& c, const Image& img, const rdr_sampler& s, uint3
     }
 }
 
-// texture(sampler2D, uv) with screen-space derivatives of uv.
+// One texel of a level: Vulkan 1.3, 16.8 nearest filtering (i = floor(u) on the unnormalised coordinate) followed by
+// the wrapping operation of the address mode.
+static void nearest(const Ctx& c, const Image& img, const rdr_sampler& s, uint32_t level, float u, float v, float out[4]) {
+    const int w = (int)mip_dim(img.w, level), h = (int)mip_dim(img.h, level);
+    const std::vector<uint8_t>& px = img.mips[level];
+    const int i = wrap_index((int)std::floor(u * (float)w), w, s.wrap_u), j = wrap_index((int)std::floor(v * (float)h), h, s.wrap_v);
+    for (int k = 0; k < 4; k++) {
+        const uint8_t q = px[((size_t)j * w + i) * 4 + k];
+        out[k] = (img.srgb && k < 3) ? c.srgb.decode[q] : (float)q / 255.0f;
+    }
+}
+
+// texture(sampler2D, uv) with screen-space derivatives of uv. The Sampler's three filters as
+// Renderer/VulkanRenderer.cpp:366-368 hands them to the driver: magFilter where lambda <= 0, minFilter above; mipmap
+// mode NEAREST takes the level ceil(lambda + 0.5) - 1, LINEAR blends floor(lambda) and the next one.
 void sample_texture(const Ctx& c, uint32_t tex, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4]) {
     const Texture& t = c.textures[tex];
     const Image& img = c.images[t.image];
+    const rdr_sampler& s = t.sampler;
     const uint32_t levels = (uint32_t)img.mips.size();
     float lambda = 0.0f;
-    if (levels > 1) {
+    bool minified = false;
+    {
         const float ax = dudx * (float)img.w, ay = dvdx * (float)img.h, bx = dudy * (float)img.w, by = dvdy * (float)img.h;
         const float rho = std::max(std::sqrt(ax * ax + ay * ay), std::sqrt(bx * bx + by * by));
-        if (rho > 1.0f) lambda = std::min(std::log2(rho), (float)(levels - 1));
+        if (rho > 1.0f) { minified = true; lambda = std::min(std::log2(rho), (float)(levels - 1)); }
     }
-    if (!(lambda > 0.0f)) { bilinear(c, img, t.sampler, 0, u, v, out); return; }
+    const bool near = (minified ? s.min_filter : s.mag_filter) == RDR_FILTER_NEAREST;
+    auto level_sample = [&](uint32_t level, float o[4]) { if (near) nearest(c, img, s, level, u, v, o); else bilinear(c, img, s, level, u, v, o); };
+    if (s.mipmap_filter == RDR_FILTER_NEAREST) {
+        level_sample((uint32_t)std::max(std::ceil(lambda + 0.5f) - 1.0f, 0.0f), out);
+        return;
+    }
+    if (!(lambda > 0.0f)) { level_sample(0, out); return; }
     const float fl = std::floor(lambda);
     const uint32_t l0 = (uint32_t)fl, l1 = std::min(l0 + 1, levels - 1);
     const float f = lambda - fl;
     float c0[4], c1[4];
-    bilinear(c, img, t.sampler, l0, u, v, c0);
-    bilinear(c, img, t.sampler, l1, u, v, c1);
+    level_sample(l0, c0);
+    level_sample(l1, c1);
     for (int k = 0; k < 4; k++) out[k] = (1.0f - f) * c0[k] + f * c1[k];
 }
 

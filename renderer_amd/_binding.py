@@ -128,7 +128,7 @@ SIGNATURES = {
     "read_env_cube": (C.c_int, [_VP, C.c_int, C.c_uint32, _FP]),
     "read_cascades": (C.c_int, [_VP, _FP, _FP]),
     "read_image_level": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _U8P, _U32P, _U32P]),
-    "post_process": (C.c_int, [_VP, _FP, C.c_float, _U8P, _FP]),
+    "post_process": (C.c_int, [_VP, _FP, C.c_float, _VP, _FP]),
 }
 
 # entry points only the HIP library has (the CPU checker allocates nothing on a device to begin with)

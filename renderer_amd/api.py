@@ -119,8 +119,9 @@ class Renderer:
                                         C.byref(out)), "load_image")
         return out.value
 
-    def make_texture(self, image, wrap_u=B.WRAP_REPEAT, wrap_v=B.WRAP_REPEAT):
-        s = B.Sampler(B.FILTER_LINEAR, B.FILTER_LINEAR, B.FILTER_LINEAR, wrap_u, wrap_v)
+    def make_texture(self, image, wrap_u=B.WRAP_REPEAT, wrap_v=B.WRAP_REPEAT, mag_filter=B.FILTER_LINEAR, min_filter=B.FILTER_LINEAR,
+                     mipmap_filter=B.FILTER_LINEAR):
+        s = B.Sampler(mag_filter, min_filter, mipmap_filter, wrap_u, wrap_v)
         out = C.c_uint32()
         self._check(self.api.make_texture(self._ctx, image, C.byref(s), C.byref(out)), "make_texture")
         return out.value
@@ -229,16 +230,22 @@ class Renderer:
     # -- the hot path -----------------------------------------------------
     def render_frame(self, exposure_mode=1, delta_time=1.0 / 60.0, temporal_luminance=0.25, exposure=0.0,
                      out=None, device_ptr=None):
-        """Renders one frame. Returns (rgba8 HxWx4 uint8 or None, avg_log_luminance)."""
+        """Renders one frame. Returns (the output image HxWx4, uint8 or with settings.hdr_output_enabled float16, or None
+        for a device destination; avg_log_luminance)."""
         fp = B.FrameParams(int(exposure_mode), float(delta_time), float(temporal_luminance), float(exposure))
         avg = C.c_float()
         if device_ptr is not None:
             self._check(self.api.render_frame(self._ctx, C.byref(fp), B._VP(int(device_ptr)), 1, None), "render_frame")
             return None, None
         if out is None:
-            out = np.empty((self.height, self.width, 4), np.uint8)
+            out = np.empty((self.height, self.width, 4), self.output_dtype)
         self._check(self.api.render_frame(self._ctx, C.byref(fp), out.ctypes.data_as(B._VP), 0, C.byref(avg)), "render_frame")
         return out, avg.value
+
+    @property
+    def output_dtype(self):
+        """R8G8B8A8_UNORM, or R16G16B16A16_SFLOAT for a context created with hdr_output_enabled."""
+        return np.float16 if self.settings.hdr_output_enabled else np.uint8
 
     def synchronize(self):
         self._check(self.api.synchronize(self._ctx), "synchronize")
@@ -255,9 +262,9 @@ class Renderer:
     def post_process(self, hdr, exposure):
         h = B.as_f32(hdr)
         assert h.shape == (self.height, self.width, 4)
-        out = np.empty((self.height, self.width, 4), np.uint8)
+        out = np.empty((self.height, self.width, 4), self.output_dtype)
         avg = C.c_float()
-        self._check(self.api.post_process(self._ctx, B.fptr(h), float(exposure), B.u8ptr(out), C.byref(avg)), "post_process")
+        self._check(self.api.post_process(self._ctx, B.fptr(h), float(exposure), out.ctypes.data_as(B._VP), C.byref(avg)), "post_process")
         return out, avg.value
 
     # -- debug read-backs -------------------------------------------------

@@ -340,11 +340,28 @@ struct TexTaps {
     float f;        // weight of the second level
     bool two;       // wave-uniform: the second level is fetched
 };
-RDR_DEV void tex_level_taps(const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level, float u, float v, TexLevelTaps& o) {
+// NEAREST within a level (Vulkan 1.3, 16.8 "nearest filtering": i = floor(u) on the unnormalised coordinate, then the
+// wrapping operation of the address mode). REPEAT on the fractional part, as in tex_axis.
+RDR_DEV int tex_axis_nearest(float coord, int n, uint32_t mode) {
+    if (mode == 0u) {
+        coord -= floorf(coord);
+        const int i = (int)floorf(coord * (float)n);  // in [0, n]: n when the product rounds up
+        return i >= n ? 0 : i;
+    }
+    return wrap_index((int)floorf(coord * (float)n), n, mode);
+}
+RDR_DEV void tex_level_taps(const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level, float u, float v, bool nearest, TexLevelTaps& o) {
     const uint32_t ww = (t.wh & 0xFFFFu) >> level, hh = (t.wh >> 16) >> level;
     const int w = (int)(ww ? ww : 1u), h = (int)(hh ? hh : 1u);
     const uint32_t base = tex_level_offset(t, table, level);
     const uint32_t flags = t.info >> 5;
+    if (nearest) {
+        // one texel, written as a footprint of four equal taps with zero weights: the filter returns it exactly
+        const int i = tex_axis_nearest(u, w, (flags >> 2) & 3u), j = tex_axis_nearest(v, h, (flags >> 4) & 3u);
+        o.o00 = o.o10 = o.o01 = o.o11 = base + (uint32_t)(mul24(j, w) + i);
+        o.a = 0.0f; o.b = 0.0f;
+        return;
+    }
     int i0, i1, j0, j1;
     tex_axis(u, w, (flags >> 2) & 3u, i0, i1, o.a);
     tex_axis(v, h, (flags >> 4) & 3u, j0, j1, o.b);
@@ -352,10 +369,37 @@ RDR_DEV void tex_level_taps(const DTexDesc& t, const DTexture* __restrict__ tabl
     o.o00 = base + (uint32_t)(r0 + i0); o.o10 = base + (uint32_t)(r0 + i1);
     o.o01 = base + (uint32_t)(r1 + i0); o.o11 = base + (uint32_t)(r1 + i1);
 }
-// texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2)
+// texture(sampler2D, uv) with screen-space uv derivatives; lambda = log2(rho) = 0.5 * log2(rho^2).
+// The Sampler's filters (VulkanRenderer.cpp:366-368 hands all three to the driver): magFilter where lambda <= 0,
+// minFilter above; mipmap mode NEAREST takes the one level ceil(lambda + 0.5) - 1, LINEAR blends floor(lambda) and the
+// next. tex_taps_filtered is the general form; tex_taps branches to it, once per wave, only when a lane's sampler has
+// a NEAREST filter, so that the all-LINEAR case pays one test for it.
+RDR_DEV void tex_taps_filtered(const DTexDesc& t, const DTexture* __restrict__ table, float u, float v, float dudx, float dvdx, float dudy,
+                               float dvdy, uint32_t nst, TexTaps& o) {
+#pragma clang fp contract(fast)
+    const uint32_t levels = t.info & 31u;
+    float lambda = 0.0f;
+    bool minified = false;
+    {
+        const float fw = (float)(t.wh & 0xFFFFu), fh = (float)(t.wh >> 16);
+        const float ax = dudx * fw, ay = dvdx * fh, bx = dudy * fw, by = dvdy * fh;
+        const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+        if (rho2 > 1.0f) { minified = true; lambda = fminf(0.5f * __log2f(rho2), (float)(levels - 1u)); }
+    }
+    if (nst & 4u) lambda = fmaxf(ceilf(lambda + 0.5f) - 1.0f, 0.0f);
+    const float fl = floorf(lambda);
+    const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, levels - 1u);
+    o.f = lambda - fl;
+    o.two = __any(o.f > 0.0f) != 0;  // a lane on a whole level blends the next one in with weight 0, which is exact
+    const bool nearest = (((minified ? nst >> 1 : nst) & 1u) != 0u);
+    tex_level_taps(t, table, l0, u, v, nearest, o.lv[0]);
+    if (o.two) tex_level_taps(t, table, l1, u, v, nearest, o.lv[1]);
+}
 RDR_DEV void tex_taps(const DTexDesc& t, const DTexture* __restrict__ table, float u, float v, float dudx, float dvdx, float dudy, float dvdy,
                       TexTaps& o) {
 #pragma clang fp contract(fast)
+    const uint32_t nst = (t.info >> (5u + RDR_TEXD_NEAREST_SHIFT)) & 7u;  // bit 0 mag, bit 1 min, bit 2 mipmap mode
+    if (__any(nst != 0u)) { tex_taps_filtered(t, table, u, v, dudx, dvdx, dudy, dvdy, nst, o); return; }
     const uint32_t levels = t.info & 31u;
     float lambda = 0.0f;
     if (levels > 1u) {
@@ -370,12 +414,12 @@ RDR_DEV void tex_taps(const DTexDesc& t, const DTexture* __restrict__ table, flo
     const float fl = floorf(lambda);
     const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, levels - 1u);
     o.f = lambda - fl;
-    tex_level_taps(t, table, l0, u, v, o.lv[0]);
-    if (o.two) tex_level_taps(t, table, l1, u, v, o.lv[1]);
+    tex_level_taps(t, table, l0, u, v, false, o.lv[0]);
+    if (o.two) tex_level_taps(t, table, l1, u, v, false, o.lv[1]);
 }
-// texture geometry = size, level count, level-offset rule and wrap modes (not the sRGB bit, not the table index)
+// texture geometry = size, level count, level-offset rule, wrap modes and filters (not the sRGB bit, not the table index)
 RDR_DEV bool tex_same_geometry(const DTexDesc& x, const DTexDesc& y) {
-    return (int)(x.wh == y.wh) & (int)(((x.info ^ y.info) & (31u | (0x3Eu << 5))) == 0u);
+    return (int)(x.wh == y.wh) & (int)(((x.info ^ y.info) & (31u | (0x1FEu << 5))) == 0u);
 }
 // Bilinear filter of four raw RGBA8 texels. sRGB channels go through the decode table before filtering; UNORM
 // channels are filtered as bytes and scaled by 1/255 once afterwards.

@@ -18,9 +18,10 @@ void launch_bloom_up(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_
 // returns true when the accumulated mips 3 and 4 were written to fin3 / fin4 instead of in place
 bool launch_bloom_chain(hipStream_t s, const void* hdr, uint32_t* const mip[6], const int w[6], const int h[6], int W, int H, uint32_t* fin3,
                         uint32_t* fin4);
-// last up-sample (mip 1 -> mip 0) fused with the tonemap; sw/sh = 0 when the image has no mip 1
+// last up-sample (mip 1 -> mip 0) fused with the tonemap; sw/sh = 0 when the image has no mip 1. `out`: RGBA8, 4 bytes
+// per pixel, or with hdr16 RGBA16F, 8 bytes per pixel
 void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* mip1, int sw, int sh, uint32_t* bloom0, uint32_t* out, float* loglum,
-                    int W, int H, float scale, float inv_gamma, float white, float log2_6, bool keep);
+                    int W, int H, float scale, float inv_gamma, float white, float log2_6, bool keep, bool hdr16);
 void launch_average_luminance(hipStream_t s, const float* loglum, int W, int H, float* l16, float* l1);
 
 // kernels_sort.hip

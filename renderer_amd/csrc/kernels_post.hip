@@ -388,12 +388,16 @@ RDR_DEV float tone(float x) {
 // tonemap.comp:45-50 for one channel. exp and pow go straight to the hardware exp2 / log2: the argument of the
 // first is <= 0 and the second sees [0, 1), so the library's range fix-ups buy nothing at 8-bit output precision.
 // `scale2` = 2^exposure * log2(e).
-RDR_DEV uint32_t tonemap_channel(float c, float bloom, float scale2, float inv_gamma, float inv_white) {
+RDR_DEV float tonemap_value(float c, float bloom, float scale2, float inv_gamma, float inv_white) {
 #pragma clang fp contract(fast)
     float v = c * (1.0f - 0.04f) + bloom * 0.04f;
     v = tone(v) * inv_white;
     v = 1.0f - __builtin_amdgcn_exp2f(-v * scale2);
-    v = __builtin_amdgcn_exp2f(inv_gamma * __builtin_amdgcn_logf(v));
+    return __builtin_amdgcn_exp2f(inv_gamma * __builtin_amdgcn_logf(v));
+}
+RDR_DEV uint32_t tonemap_channel(float c, float bloom, float scale2, float inv_gamma, float inv_white) {
+#pragma clang fp contract(fast)
+    const float v = tonemap_value(c, bloom, scale2, inv_gamma, inv_white);
     return (uint32_t)(int)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f);  // UNORM8, NaN -> 0
 }
 
@@ -423,8 +427,9 @@ RDR_DEV void tent_accumulate_h(const TentH& t, float& acc0, float& acc1, float& 
 // `inv_white` = 1 / tone(11.2) from the host. VEC: the image width is even, so the two pixels of a quad row are
 // one 16-byte load and 8-byte stores. KEEP: also store the accumulated mip 0 and the whole log-luminance image (the
 // shader writes both; nothing later in the frame reads mip 0, and the average-luminance pass reads only the centre
-// crop [cx0, cx1] x [cy0, cy1] of the log-luminance, which is always stored).
-template <bool VEC, bool KEEP>
+// crop [cx0, cx1] x [cy0, cy1] of the log-luminance, which is always stored). HDR16: the output image is RGBA16F
+// (hdrOutputEnabled, VulkanRenderer.cpp:668-673): `out` then holds 8 bytes per pixel, the same values unquantised.
+template <bool VEC, bool KEEP, bool HDR16>
 __global__ void __launch_bounds__(256) k_tonemap(const uint2* __restrict__ hdr, const uint32_t* __restrict__ mip1, int sw, int sh,
                                                  uint32_t* __restrict__ bloom0, uint32_t* __restrict__ out, float* __restrict__ loglum,
                                                  int W, int H, float scale2, float inv_gamma, float inv_white, float log2_6, int cx0, int cx1,
@@ -443,6 +448,7 @@ __global__ void __launch_bounds__(256) k_tonemap(const uint2* __restrict__ hdr, 
         if (VEC) { const uint4 v = *(const uint4*)(hdr + i0); h[0] = make_uint2(v.x, v.y); h[1] = make_uint2(v.z, v.w); }
         else { h[0] = hdr[i0]; h[1] = (2 * qx + 1 < W) ? hdr[i0 + 1] : make_uint2(0u, 0u); }
         uint32_t b0[2] = {0u, 0u}, px[2];
+        uint2 hp[2];
         float ll[2];
 #pragma unroll
         for (int ox = 0; ox < 2; ox++) {
@@ -467,21 +473,28 @@ __global__ void __launch_bounds__(256) k_tonemap(const uint2* __restrict__ hdr, 
                 bl[0] = (float)rg.x; bl[1] = (float)rg.y; bl[2] = (float)bb.x;
             }
             ll[ox] = __builtin_amdgcn_logf((2.0f * c[0] + 3.0f * c[1]) + c[2]) - log2_6;
-            px[ox] = 0xFF000000u | tonemap_channel(c[0], bl[0], scale2, inv_gamma, inv_white) |
-                     (tonemap_channel(c[1], bl[1], scale2, inv_gamma, inv_white) << 8) |
-                     (tonemap_channel(c[2], bl[2], scale2, inv_gamma, inv_white) << 16);
+            if (HDR16)
+                hp[ox] = pack_half4(tonemap_value(c[0], bl[0], scale2, inv_gamma, inv_white), tonemap_value(c[1], bl[1], scale2, inv_gamma, inv_white),
+                                    tonemap_value(c[2], bl[2], scale2, inv_gamma, inv_white), 1.0f);
+            else
+                px[ox] = 0xFF000000u | tonemap_channel(c[0], bl[0], scale2, inv_gamma, inv_white) |
+                         (tonemap_channel(c[1], bl[1], scale2, inv_gamma, inv_white) << 8) |
+                         (tonemap_channel(c[2], bl[2], scale2, inv_gamma, inv_white) << 16);
         }
         const bool lum = KEEP || (y >= cy0 && y <= cy1 && 2 * qx + 1 >= cx0 && 2 * qx <= cx1);
         if (VEC) {
             if (KEEP) *(uint2*)(bloom0 + i0) = make_uint2(b0[0], b0[1]);
-            *(uint2*)(out + i0) = make_uint2(px[0], px[1]);
+            if (HDR16) *(uint4*)((uint2*)out + i0) = make_uint4(hp[0].x, hp[0].y, hp[1].x, hp[1].y);
+            else *(uint2*)(out + i0) = make_uint2(px[0], px[1]);
             if (lum) *(float2*)(loglum + i0) = make_float2(ll[0], ll[1]);
         } else {
-            out[i0] = px[0];
+            if (HDR16) ((uint2*)out)[i0] = hp[0];
+            else out[i0] = px[0];
             if (KEEP) bloom0[i0] = b0[0];
             if (lum) loglum[i0] = ll[0];
             if (2 * qx + 1 < W) {
-                out[i0 + 1] = px[1];
+                if (HDR16) ((uint2*)out)[i0 + 1] = hp[1];
+                else out[i0 + 1] = px[1];
                 if (KEEP) bloom0[i0 + 1] = b0[1];
                 if (lum) loglum[i0 + 1] = ll[1];
             }
@@ -568,17 +581,19 @@ bool launch_bloom_chain(hipStream_t s, const void* hdr, uint32_t* const mip[6], 
     return false;
 }
 void launch_tonemap(hipStream_t s, const void* hdr, const uint32_t* mip1, int sw, int sh, uint32_t* bloom0, uint32_t* out, float* loglum,
-                    int W, int H, float scale, float inv_gamma, float white, float log2_6, bool keep) {
+                    int W, int H, float scale, float inv_gamma, float white, float log2_6, bool keep, bool hdr16) {
     const int qw = (W + 1) / 2, qh = (H + 1) / 2;
     const float scale2 = scale * 1.44269504088896340736f;  // exp(-x s) = exp2(-x s log2 e)
     const dim3 grid((qw + 63) / 64, (qh + 3) / 4);
     // what launch_average_luminance reads: 256 x 256 texels from (W/2 - 128, H/2 - 128), coordinates clamped to the image
     const int cx0 = max(W / 2 - 128, 0), cx1 = min(W / 2 + 127, W - 1), cy0 = max(H / 2 - 128, 0), cy1 = min(H / 2 + 127, H - 1);
-#define RDR_TONEMAP(VEC, KEEP)                                                                                                          \
-    hipLaunchKernelGGL((k_tonemap<VEC, KEEP>), grid, dim3(256), 0, s, (const uint2*)hdr, mip1, sw, sh, bloom0, out, loglum, W, H, scale2, \
+#define RDR_TONEMAP(VEC, KEEP, HDR16)                                                                                                          \
+    hipLaunchKernelGGL((k_tonemap<VEC, KEEP, HDR16>), grid, dim3(256), 0, s, (const uint2*)hdr, mip1, sw, sh, bloom0, out, loglum, W, H, scale2, \
                        inv_gamma, 1.0f / white, log2_6, cx0, cx1, cy0, cy1)
-    if ((W & 1) == 0) { if (keep) RDR_TONEMAP(true, true); else RDR_TONEMAP(true, false); }
-    else { if (keep) RDR_TONEMAP(false, true); else RDR_TONEMAP(false, false); }
+#define RDR_TONEMAP_OUT(VEC, KEEP) do { if (hdr16) RDR_TONEMAP(VEC, KEEP, true); else RDR_TONEMAP(VEC, KEEP, false); } while (0)
+    if ((W & 1) == 0) { if (keep) RDR_TONEMAP_OUT(true, true); else RDR_TONEMAP_OUT(true, false); }
+    else { if (keep) RDR_TONEMAP_OUT(false, true); else RDR_TONEMAP_OUT(false, false); }
+#undef RDR_TONEMAP_OUT
 #undef RDR_TONEMAP
 }
 void launch_average_luminance(hipStream_t s, const float* loglum, int W, int H, float* l16, float* l1) {

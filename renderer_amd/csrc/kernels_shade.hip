@@ -249,7 +249,8 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
         const uint32_t ti = mt.tex[k] != 0xFFFFFFFFu ? mt.tex[k] : (k == 1 ? fr.tex_normal : fr.tex_white);
         const DTexture& t = fr.textures[ti];
         const bool pow2sq = t.w == t.h && (t.w & (t.w - 1u)) == 0u && (t.levels == 1u || (1u << (t.levels - 1u)) == t.w);
-        const uint32_t flags = (t.flags & 1u) | (pow2sq ? RDR_TEXD_POW2_SQUARE : 0u) | (((t.flags >> 4) & 3u) << 2) | (((t.flags >> 8) & 3u) << 4);
+        const uint32_t flags = (t.flags & 1u) | (pow2sq ? RDR_TEXD_POW2_SQUARE : 0u) | (((t.flags >> 4) & 3u) << 2) | (((t.flags >> 8) & 3u) << 4) |
+                               (((t.flags >> 12) & 7u) << RDR_TEXD_NEAREST_SHIFT);
         o.tex[k].base = t.base;
         o.tex[k].wh = t.w | (t.h << 16);
         o.tex[k].info = t.levels | (flags << 5) | (ti << 16);

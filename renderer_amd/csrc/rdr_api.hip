@@ -575,7 +575,9 @@ int upload_scene(rdr_ctx* c) {
             memset(&d, 0, sizeof d);
             d.base = (const uint8_t*)img.pixels.p;
             d.w = img.w; d.h = img.h; d.levels = img.levels;
-            d.flags = (img.srgb ? 1u : 0u) | (t.sampler.wrap_u << 4) | (t.sampler.wrap_v << 8);
+            const uint32_t nearest = (t.sampler.mag_filter == RDR_FILTER_NEAREST ? 1u : 0u) | (t.sampler.min_filter == RDR_FILTER_NEAREST ? 2u : 0u) |
+                                     (t.sampler.mipmap_filter == RDR_FILTER_NEAREST ? 4u : 0u);
+            d.flags = (img.srgb ? 1u : 0u) | (t.sampler.wrap_u << 4) | (t.sampler.wrap_v << 8) | (nearest << 12);
             memcpy(d.level_offset, img.level_offset, sizeof d.level_offset);
         }
         HIP_TRY(c->d_textures.ensure(dt.size() * sizeof(DTexture)));
@@ -1164,6 +1166,11 @@ float tone_curve(float x) {  // tonemap.comp:26-28
     return ((x * (shoulderStr * x + linAngle * linStr) + toeStr * toeNum) / (x * (shoulderStr * x + linStr) + toeStr * toeDenom)) - toeNum / toeDenom;
 }
 
+// The output image: R8G8B8A8_UNORM, or R16G16B16A16_SFLOAT with hdrOutputEnabled (VulkanRenderer.cpp:668-676: the
+// float format a presentation surface offers). The tonemap kernel stores two pixels at a time.
+size_t out_pixel_bytes(const rdr_ctx* c) { return c->settings.hdr_output_enabled ? 8u : 4u; }
+uintptr_t out_align(const rdr_ctx* c) { return c->settings.hdr_output_enabled ? 16u : 8u; }
+
 int ensure_post_targets(rdr_ctx* c) {
     const size_t n = (size_t)c->W * c->H;
     HIP_TRY(c->d_hdr.ensure(n * 8));
@@ -1177,14 +1184,15 @@ int ensure_post_targets(rdr_ctx* c) {
     c->bloom_fin_offset[0] = (uint32_t)off; off += ((size_t)c->bloom_w[3] * c->bloom_h[3] + 3u) & ~(size_t)3u;
     c->bloom_fin_offset[1] = (uint32_t)off; off += (size_t)c->bloom_w[4] * c->bloom_h[4];
     HIP_TRY(c->d_bloom.ensure(off * 4));
-    HIP_TRY(c->d_out.ensure(n * 4));
+    HIP_TRY(c->d_out.ensure(n * out_pixel_bytes(c)));
     HIP_TRY(c->d_loglum.ensure(n * 4));
     HIP_TRY(c->d_lum.ensure((256 + 16) * 4));
     return RDR_OK;
 }
 
 // bloom chain + tonemap + average luminance (VulkanRendererBloom.cpp:62-100, VulkanRenderer.cpp:1084-1109, 1156-1191)
-// `direct_out`: a device destination the tonemap kernel writes the finished frame to instead of d_out (8-byte aligned)
+// `direct_out`: a device destination the tonemap kernel writes the finished frame to instead of d_out (aligned to
+// out_align(c) bytes)
 void enqueue_post(rdr_ctx* c, hipStream_t st, float exposure, uint32_t* direct_out = nullptr) {
     uint32_t* bloom = c->d_bloom.as<uint32_t>();
     (void)hipEventRecord(c->ev[2], st);
@@ -1196,7 +1204,7 @@ void enqueue_post(rdr_ctx* c, hipStream_t st, float exposure, uint32_t* direct_o
     (void)hipEventRecord(c->ev[3], st);
     launch_tonemap(st, c->d_hdr.p, bloom + c->bloom_offset[1], (int)c->bloom_w[1], (int)c->bloom_h[1], bloom, direct_out ? direct_out : c->d_out.as<uint32_t>(),
                    c->d_loglum.as<float>(), (int)c->W, (int)c->H, powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f),
-                   c->keep_intermediates);
+                   c->keep_intermediates, c->settings.hdr_output_enabled != 0);
     c->post_kept = c->keep_intermediates;
     launch_average_luminance(st, c->d_loglum.as<float>(), (int)c->W, (int)c->H, c->d_lum.as<float>(), (float*)frame_counters(c) + RDR_COUNTER_LUM);
     (void)hipEventRecord(c->ev[4], st);
@@ -1221,9 +1229,9 @@ int rdr_create(const rdr_settings* settings, uint32_t width, uint32_t height, in
     if ((settings->msaa != 1 && settings->msaa != 4) || settings->directional_shadow_cascade_levels < 1 ||
         settings->directional_shadow_cascade_levels > RDR_MAX_CASCADES)
         return RDR_ERR_UNSUPPORTED;
-    // what the implementation does not offer is refused, not ignored: an HDR output image (VulkanRenderer.h:45), shadow
-    // maps whose tile boxes would not fit 16-bit coordinates, more cube slots than a frame can reasonably hold
-    if (settings->hdr_output_enabled) return RDR_ERR_UNSUPPORTED;
+    // what the implementation does not offer is refused, not ignored: shadow maps whose tile boxes would not fit 16-bit
+    // coordinates, more cube slots than a frame can reasonably hold
+    if (settings->hdr_output_enabled > 1) return RDR_ERR_INVALID;
     if (settings->directional_shadow_map_resolution == 0 || settings->point_shadow_map_resolution == 0) return RDR_ERR_INVALID;
     if (settings->directional_shadow_map_resolution > 16384 || settings->point_shadow_map_resolution > 8192 || settings->point_shadow_map_count > 64)
         return RDR_ERR_UNSUPPORTED;
@@ -1363,8 +1371,8 @@ int rdr_load_image(rdr_ctx* c, const void* ptr, size_t size, uint32_t w, uint32_
 
 int rdr_make_texture(rdr_ctx* c, uint32_t image, const rdr_sampler* s, uint32_t* out_id) {
     if (!c || !s || !out_id || image >= c->images.size()) return fail(c, RDR_ERR_INVALID, "make_texture: bad argument");
-    if (s->mag_filter != RDR_FILTER_LINEAR || s->min_filter != RDR_FILTER_LINEAR || s->mipmap_filter != RDR_FILTER_LINEAR)
-        return fail(c, RDR_ERR_UNSUPPORTED, "make_texture: only LINEAR filters are supported");
+    if (s->mag_filter > RDR_FILTER_LINEAR || s->min_filter > RDR_FILTER_LINEAR || s->mipmap_filter > RDR_FILTER_LINEAR)
+        return fail(c, RDR_ERR_INVALID, "make_texture: bad filter");
     if (s->wrap_u > RDR_WRAP_CLAMP || s->wrap_v > RDR_WRAP_CLAMP) return fail(c, RDR_ERR_INVALID, "make_texture: bad wrap mode");
     // VulkanRenderer.cpp:370-371: the V address mode is REPEAT if wrapV says so; otherwise it is chosen by wrapU (the
     // reference tests wrapU for "mirror" in both lines), so (REPEAT, MIRROR) samples V clamped and (MIRROR, CLAMP)
@@ -2097,8 +2105,8 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         c->host_wait_s += host_now() - t_wait;
     }
     const float exposure = compute_exposure(c, fp);
-    // a device destination receives the frame straight from the tonemap kernel (its 8-byte stores need the alignment)
-    uint32_t* direct_out = (out_rgba8 && out_is_device && ((uintptr_t)out_rgba8 & 7u) == 0) ? (uint32_t*)out_rgba8 : nullptr;
+    // a device destination receives the frame straight from the tonemap kernel (its two-pixel stores need the alignment)
+    uint32_t* direct_out = (out_rgba8 && out_is_device && ((uintptr_t)out_rgba8 & (out_align(c) - 1u)) == 0) ? (uint32_t*)out_rgba8 : nullptr;
     HIP_TRY(hipEventRecord(c->ev_shaded[c->slot], ts));  // the shadow maps and the geometry phase's outputs have been read
     HIP_TRY(hipStreamWaitEvent(c->stream4, c->ev_shaded[c->slot], 0));  // the tail has its own stream: the next frame's shading does not queue behind it
     enqueue_post(c, c->stream4, exposure, direct_out);
@@ -2110,7 +2118,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     HIP_TRY(hipMemcpyAsync(c->h_read.as<uint8_t>() + (size_t)c->slot * RDR_COUNTER_BYTES, frame_counters(c), RDR_COUNTER_BYTES,
                            hipMemcpyDeviceToHost, c->stream4));
     if (out_rgba8 && !direct_out)
-        HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream4));
+        HIP_TRY(hipMemcpyAsync(out_rgba8, c->d_out.p, n * out_pixel_bytes(c), out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream4));
     HIP_TRY(hipEventRecord(c->ev[5], c->stream4));
     // host time of this frame: everything this call did up to here, less the time it sat waiting for the GPU
     c->stats.host_ms = (float)((host_now() - t_enter - c->host_wait_s) * 1e3);
@@ -2338,7 +2346,7 @@ int rdr_post_process(rdr_ctx* c, const float* hdr, float exposure, uint8_t* out_
     enqueue_post(c, c->stream, exposure);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, c->d_out.p, n * 4, hipMemcpyDeviceToHost));
+    if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, c->d_out.p, n * out_pixel_bytes(c), hipMemcpyDeviceToHost));
     if (out_avg) HIP_TRY(hipMemcpy(out_avg, (float*)frame_counters(c) + RDR_COUNTER_LUM, 4, hipMemcpyDeviceToHost));
     return RDR_OK;
 }
@@ -2349,8 +2357,8 @@ int rdr_post_process_noalloc(rdr_ctx* c, const void* hdr_rgba16f, uint32_t width
     if (width == 0 || height == 0) return fail(c, RDR_ERR_INVALID, "post_process_noalloc: empty image");
     if ((uint64_t)width * height > RDR_NOALLOC_MAX_PIXELS)
         return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: more than RDR_NOALLOC_MAX_PIXELS pixels; use rdr_post_process");
-    if (((uintptr_t)hdr_rgba16f & 15u) || ((uintptr_t)out_rgba8 & 7u) || ((uintptr_t)out_avg & 3u))
-        return fail(c, RDR_ERR_INVALID, "post_process_noalloc: hdr must be 16-byte, out 8-byte, avg 4-byte aligned");
+    if (((uintptr_t)hdr_rgba16f & 15u) || ((uintptr_t)out_rgba8 & (out_align(c) - 1u)) || ((uintptr_t)out_avg & 3u))
+        return fail(c, RDR_ERR_INVALID, "post_process_noalloc: hdr must be 16-byte, out 8-byte (16-byte for an RGBA16F output), avg 4-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     // carve the scratch array: six bloom mips | log-luminance image | 256 + 16 partial means
@@ -2374,7 +2382,7 @@ int rdr_post_process_noalloc(rdr_ctx* c, const void* hdr_rgba16f, uint32_t width
     for (int k = 0; k < 6; k++) { mip[k] = bloom + off[k]; mw[k] = (int)bw[k]; mh[k] = (int)bh[k]; }
     launch_bloom_chain(st, hdr_rgba16f, mip, mw, mh, (int)width, (int)height, bloom + words, bloom + fin4_at);
     launch_tonemap(st, hdr_rgba16f, bloom + off[1], (int)bw[1], (int)bh[1], bloom, (uint32_t*)out_rgba8, loglum, (int)width, (int)height,
-                   powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f), false);
+                   powf(2.0f, exposure), 1.0f / c->settings.gamma, tone_curve(11.2f), log2f(6.0f), false, c->settings.hdr_output_enabled != 0);
     launch_average_luminance(st, loglum, (int)width, (int)height, lum, out_avg);
     HIP_TRY(hipGetLastError());
     return RDR_OK;

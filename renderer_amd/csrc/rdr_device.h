@@ -46,7 +46,7 @@ struct DVertexAttr {
 struct DTexture {
     const uint8_t* base;
     uint32_t w, h, levels;
-    uint32_t flags;  // bit0 sRGB, bits 4..5 wrap_u, bits 8..9 wrap_v
+    uint32_t flags;  // bit0 sRGB, bits 4..5 wrap_u, bits 8..9 wrap_v, bits 12..14 NEAREST for mag / min / mipmap mode
     uint32_t level_offset[RDR_MAX_TEX_LEVELS];  // in texels
 };
 
@@ -119,10 +119,11 @@ struct DTriRec {
 // Compact texture descriptor inside a DShadeTri: everything a fetch needs without another table look-up.
 #define RDR_TEXD_SRGB 1u        // flags bit 0
 #define RDR_TEXD_POW2_SQUARE 2u  // flags bit 1: w == h == 2^n with a complete chain, level offsets are arithmetic
+#define RDR_TEXD_NEAREST_SHIFT 6u  // flags bits 6..8: the Sampler's magFilter / minFilter / mipmapFilter is NEAREST
 struct DTexDesc {
     const uint8_t* base;  // RGBA8 texels, all levels
     uint32_t wh;          // w | h << 16
-    uint32_t info;        // levels (5 bits) | flags << 5 (srgb, pow2-square, wrap_u << 2, wrap_v << 4) | texture index << 16
+    uint32_t info;        // levels (5 bits) | flags << 5 (srgb, pow2-square, wrap_u << 2, wrap_v << 4, nearest filters << 6) | texture index << 16
 };  // 16 bytes
 
 // Everything the fragments of one triangle share: the vertex-stage outputs

@@ -8,7 +8,8 @@ Follows the reference where it has a behaviour of its own:
     from the POSITION accessor's min / max (main.cpp:382-385);
   - materials map as main.cpp:135-166: base colour texture sampled as sRGB, the others as UNORM; a missing normal
     texture selects the renderer's default (128,128,255); ao factor = occlusionTexture.strength; alpha mode and
-    cut-off as given;
+    cut-off as given; a texture's sampler (wrap modes, filters; the reference's loader uses one default sampler) becomes
+    the Sampler of makeTexture (VulkanRenderer.cpp:363-385), a minFilter without mip-mapping an image of one level;
   - all channels of all animations are attached to their nodes, with the MIRROR repeat mode main.cpp:260-276 uses.
 Departs from it where the reference is wrong or silent: node rotations are quaternions (main.cpp:207-209 reads three
 components as Euler angles), interpolation follows the specification (see animation.py), and skins are read.
@@ -33,6 +34,12 @@ CONTAINER = {"SCALAR": (B.SCALAR, 1), "VEC2": (B.VEC2, 2), "VEC3": (B.VEC3, 3), 
 ATTRIBUTES = {"POSITION": B.ATTR_POSITION, "NORMAL": B.ATTR_NORMAL, "TANGENT": B.ATTR_TANGENT, "TEXCOORD_0": B.ATTR_TEXCOORD_0,
               "JOINTS_0": B.ATTR_JOINTS_0, "WEIGHTS_0": B.ATTR_WEIGHTS_0}
 WRAP = {10497: B.WRAP_REPEAT, 33648: B.WRAP_MIRROR, 33071: B.WRAP_CLAMP}
+# glTF sampler.minFilter -> (minFilter, mipmapFilter, whether the image gets a mip chain); magFilter 9728 / 9729 -> filter.
+# A sampler without the property leaves the choice to the loader: the reference's own, LINEAR everywhere with mips.
+MIN_FILTER = {9728: (B.FILTER_NEAREST, B.FILTER_NEAREST, False), 9729: (B.FILTER_LINEAR, B.FILTER_NEAREST, False),
+              9984: (B.FILTER_NEAREST, B.FILTER_NEAREST, True), 9985: (B.FILTER_LINEAR, B.FILTER_NEAREST, True),
+              9986: (B.FILTER_NEAREST, B.FILTER_LINEAR, True), 9987: (B.FILTER_LINEAR, B.FILTER_LINEAR, True)}
+MAG_FILTER = {9728: B.FILTER_NEAREST, 9729: B.FILTER_LINEAR}
 ALPHA = {"OPAQUE": B.ALPHA_OPAQUE, "MASK": B.ALPHA_MASK, "BLEND": B.ALPHA_BLEND}
 
 
@@ -159,8 +166,8 @@ class _Loader:
         return out
 
     # -- images, textures, materials -----------------------------------------
-    def image_id(self, index, srgb):
-        key = (index, srgb)
+    def image_id(self, index, srgb, mips=True):
+        key = (index, srgb, mips)
         if key not in self.image_ids:
             img = self.doc["images"][index]
             if "uri" in img:
@@ -170,7 +177,8 @@ class _Loader:
                 o = view.get("byteOffset", 0)
                 data = self.buffers_raw[view["buffer"]][o:o + view["byteLength"]]
             pixels = np.asarray(PILImage.open(io.BytesIO(data)).convert("RGBA"))
-            self.image_ids[key] = self.r.load_image(pixels, B.FORMAT_R8G8B8A8_SRGB if srgb else B.FORMAT_R8G8B8A8_UNORM)
+            self.image_ids[key] = self.r.load_image(pixels, B.FORMAT_R8G8B8A8_SRGB if srgb else B.FORMAT_R8G8B8A8_UNORM,
+                                                    0xFFFFFFFF if mips else 1)
         return self.image_ids[key]
 
     def texture_id(self, info, srgb=False):
@@ -181,9 +189,12 @@ class _Loader:
             return B.INVALID_ID
         smp = self.doc.get("samplers", [])[tex["sampler"]] if "sampler" in tex else {}
         wrap = (WRAP.get(smp.get("wrapS", 10497), B.WRAP_REPEAT), WRAP.get(smp.get("wrapT", 10497), B.WRAP_REPEAT))
-        key = (tex["source"], srgb, wrap)
+        min_filter, mipmap_filter, mips = MIN_FILTER.get(smp.get("minFilter"), (B.FILTER_LINEAR, B.FILTER_LINEAR, True))
+        mag_filter = MAG_FILTER.get(smp.get("magFilter"), B.FILTER_LINEAR)
+        key = (tex["source"], srgb, wrap, mag_filter, min_filter, mipmap_filter, mips)
         if key not in self.texture_ids:
-            self.texture_ids[key] = self.r.make_texture(self.image_id(tex["source"], srgb), wrap[0], wrap[1])
+            self.texture_ids[key] = self.r.make_texture(self.image_id(tex["source"], srgb, mips), wrap[0], wrap[1], mag_filter, min_filter,
+                                                        mipmap_filter)
         return self.texture_ids[key]
 
     def material(self, index):

@@ -62,10 +62,12 @@ class FrameSharder:
         self.frames_rendered = 0
         self.depth = max(1, int(depth))
         H, W = renderer.height, renderer.width
-        self.slots = [torch.empty((H, W, 4), dtype=torch.uint8, device=self.device) for _ in range(self.depth)]
+        # the renderer's output image: RGBA8, or RGBA16F for a context created with hdr_output_enabled
+        pixel = torch.float16 if renderer.settings.hdr_output_enabled else torch.uint8
+        self.slots = [torch.empty((H, W, 4), dtype=pixel, device=self.device) for _ in range(self.depth)]
         self.recv = None
         if dist and self.rank == 0:
-            self.recv = [[torch.empty((H, W, 4), dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+            self.recv = [[torch.empty((H, W, 4), dtype=pixel, device=self.device) for _ in range(self.world)]
                          for _ in range(self.depth)]
         self.pending = [None] * self.depth   # (work handle, round index) per slot
         self.luminance = {}

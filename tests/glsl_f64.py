@@ -280,22 +280,61 @@ def texture_lod(levels, dudx, dvdx, dudy, dvdy):
     return np.clip(lam, 0.0, len(levels) - 1.0)
 
 
-def texture_2d(levels, u, v, dudx, dvdx, dudy, dvdy, modes=(REPEAT, REPEAT)):
-    """texture(sampler2D, uv) with mag/min LINEAR, mipmap mode LINEAR (VulkanRenderer.cpp:363-385) and the address modes
-    `modes`: the two levels around lambda, each filtered bilinearly, blended by the fraction. `levels`: decoded float
-    texels per mip level. Returns (value [n, C], lambda [n])."""
-    lam = texture_lod(levels, dudx, dvdx, dudy, dvdy)
-    l0 = np.floor(lam).astype(np.int64)
-    l1 = np.minimum(l0 + 1, len(levels) - 1)
-    f = (lam - l0)[..., None]
+FILTER_NEAREST, FILTER_LINEAR = 0, 1
+
+
+def nearest_texel(level, u, v, modes=(REPEAT, REPEAT), eps=0.02):
+    """NEAREST filter on one level (Vulkan 1.3 "Texel Filtering": i = floor(u) on the unnormalised coordinate, then the
+    wrapping operation). Returns (texels, robust): robust is False within `eps` texels of a texel boundary."""
+    h, w = level.shape[:2]
+    x, y = u * w, v * h
+    i, j = np.floor(x), np.floor(y)
+    fx, fy = x - i, y - j
+    ok = (np.minimum(fx, 1 - fx) > eps) & (np.minimum(fy, 1 - fy) > eps)
+    return level[wrap_texel(j.astype(np.int64), h, modes[1]), wrap_texel(i.astype(np.int64), w, modes[0])], ok
+
+
+def texture_2d(levels, u, v, dudx, dvdx, dudy, dvdy, modes=(REPEAT, REPEAT), filters=(FILTER_LINEAR, FILTER_LINEAR, FILTER_LINEAR)):
+    """texture(sampler2D, uv) with the address modes `modes` and the Sampler's `filters` = (magFilter, minFilter,
+    mipmapFilter) as VulkanRenderer.cpp:363-385 hands them to the driver. Vulkan 1.3: lambda = log2(rho) clamped to the
+    chain; the filter within a level is magFilter where lambda <= 0 and minFilter above; mipmap mode LINEAR blends the
+    two levels around lambda by its fraction, NEAREST takes the level ceil(lambda + 0.5) - 1. `levels`: decoded float
+    texels per mip level. Returns (value [n, C], lambda [n], robust [n]): robust is False where a discontinuous choice
+    (filter switch, level rounding, nearest texel) is decided by a margin a float32 implementation may not resolve."""
+    mag, mnf, mip = filters
+    q = len(levels) - 1
+    h0, w0 = levels[0].shape[:2]
+    rho = np.maximum(np.hypot(dudx * w0, dvdx * h0), np.hypot(dudy * w0, dvdy * h0))
+    with np.errstate(divide="ignore"):
+        raw = np.log2(rho)
+    lam = np.clip(raw, 0.0, float(q))
+    robust = np.ones(np.shape(u), bool)
+    minified = raw > 0.0
+    if mag != mnf:
+        robust &= np.abs(raw) > 0.02
+    use_nearest = np.where(minified, mnf == FILTER_NEAREST, mag == FILTER_NEAREST)
+    if mip == FILTER_NEAREST:
+        d = np.maximum(np.ceil(lam + 0.5) - 1.0, 0.0)
+        inner = (lam > 0.0) & (lam < q)
+        robust &= ~inner | (np.abs(lam + 0.5 - np.round(lam + 0.5)) > 0.02)
+        l0 = l1 = d.astype(np.int64)
+        f = np.zeros(np.shape(u))[..., None]
+    else:
+        l0 = np.floor(lam).astype(np.int64)
+        l1 = np.minimum(l0 + 1, q)
+        f = (lam - l0)[..., None]
     out = np.zeros(np.shape(u) + (levels[0].shape[-1],))
     for lv in range(len(levels)):
-        m0, m1 = l0 == lv, l1 == lv
+        m0, m1 = l0 == lv, (l1 == lv) & (f[..., 0] > 0.0)
         if not (m0.any() or m1.any()):
             continue
         val = bilinear_repeat(levels[lv], u, v, modes)
+        if use_nearest.any():
+            near, ok = nearest_texel(levels[lv], u, v, modes)
+            val = np.where(use_nearest[..., None], near, val)
+            robust &= ~(use_nearest & (m0 | m1)) | ok
         out = out + np.where(m0[..., None], (1 - f) * val, 0.0) + np.where(m1[..., None], f * val, 0.0)
-    return out, lam
+    return out, lam, robust
 
 
 def blit_linear(src_u8, dw, dh, srgb):
@@ -392,13 +431,15 @@ def material_samples(frag, mat):
     chains (`chains`: name -> list of uint8 levels) sampled at the fragments' uv with their derivatives."""
     n = frag["world"].shape[0]
     names = ("albedo", "normal", "metal_rough", "ao_tex", "emissive_tex")
-    out = {}
+    out = {"robust": np.ones(n, bool)}
     for name in names:
         srgb = name == "albedo"
         if mat.get("chains"):
             levels = [decode_texels(lv, srgb) for lv in mat["chains"][name]]
-            out[name], _ = texture_2d(levels, frag["uv"][:, 0], frag["uv"][:, 1], frag["duvdx"][:, 0], frag["duvdx"][:, 1],
-                                      frag["duvdy"][:, 0], frag["duvdy"][:, 1], reference_address_modes(*mat.get("wrap", (REPEAT, REPEAT))))
+            out[name], _, ok = texture_2d(levels, frag["uv"][:, 0], frag["uv"][:, 1], frag["duvdx"][:, 0], frag["duvdx"][:, 1],
+                                          frag["duvdy"][:, 0], frag["duvdy"][:, 1], reference_address_modes(*mat.get("wrap", (REPEAT, REPEAT))),
+                                          mat.get("filters", (FILTER_LINEAR, FILTER_LINEAR, FILTER_LINEAR)))
+            out["robust"] = out["robust"] & ok
         else:
             out[name] = np.broadcast_to(decode_texels(np.asarray(mat[name], np.uint8), srgb), (n, 4))
     return out
@@ -411,15 +452,15 @@ def pbr_frag(frag, mat, scene):
           ls (n_cascades, 3) = directionalLightSpaceCoords; for mip-mapped materials also uv (2) and its forward
           differences duvdx, duvdy (2 each).
     mat:  dict: base_color (4), emissive (3), metallic, roughness, ao, alpha_mode, alpha_cutoff and its five textures
-          (see material_samples).
+          (see material_samples); optionally wrap (wrapU, wrapV) and filters (mag, min, mipmap) of its Sampler.
     scene: dict: cam (3), point_lights [(pos, intensity, cube)] where cube is None for a light without a shadow map
           and its six depth faces [6, r, r] otherwise, dir_direction (3), dir_intensity (3),
           cascades: list of depth maps, prefiltered: list of cube levels, irradiance: cube, lut: uint8 [h, w, >=2].
     Returns (rgba [n, 4], robust [n], info) with info["point_shadow"][i] = the shadow factor of light i per fragment
     (NaN where the light was skipped before its look-up)."""
     n = frag["world"].shape[0]
-    robust = np.ones(n, bool)
     tex = material_samples(frag, mat)
+    robust = tex["robust"].copy()
     albedo = tex["albedo"] * np.asarray(mat["base_color"], np.float64)                      # :95
     masked = np.zeros(n, bool)
     if mat["alpha_mode"] == 1:                                                              # :96-99

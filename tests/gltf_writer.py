@@ -81,8 +81,8 @@ class GltfWriter:
         self.doc["images"].append(entry)
         return len(self.doc["images"]) - 1, data
 
-    def texture(self, image, wrap_s=10497, wrap_t=10497):
-        self.doc["samplers"].append({"magFilter": 9729, "minFilter": 9987, "wrapS": wrap_s, "wrapT": wrap_t})
+    def texture(self, image, wrap_s=10497, wrap_t=10497, mag_filter=9729, min_filter=9987):
+        self.doc["samplers"].append({"magFilter": mag_filter, "minFilter": min_filter, "wrapS": wrap_s, "wrapT": wrap_t})
         self.doc["textures"].append({"source": image, "sampler": len(self.doc["samplers"]) - 1})
         return len(self.doc["textures"]) - 1
 

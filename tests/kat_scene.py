@@ -94,9 +94,19 @@ def _chain_images(size, seed, crop=None, **kw):
     return dict(zip(("albedo", "normal", "metal_rough", "ao_tex", "emissive_tex"), imgs))
 
 
-def detail_prims():
+LIN, NEAR = B.FILTER_LINEAR, B.FILTER_NEAREST
+# the "filters" variant: the Sampler's (magFilter, minFilter, mipmapFilter) per primitive of the "detail" scene
+FILTERS = dict(ground=(LIN, LIN, NEAR),    # minified over many levels: one level at a time, bilinear within it
+               box=(NEAR, LIN, LIN),       # magnified: single texels
+               wall=(LIN, NEAR, LIN),      # minified: one texel from each of the two levels around lambda, blended
+               mover=(NEAR, NEAR, LIN),
+               card=(NEAR, NEAR, NEAR))    # the textured alpha of the MASK card, unfiltered
+
+
+def detail_prims(filters=None):
     """Opaque primitives, then MASK / BLEND ones, of the "detail" variant. `images` holds level 0 of the five textures;
-    the chains are read back from the renderer (build() stores the image ids)."""
+    the chains are read back from the renderer (build() stores the image ids). `filters`: None for LINEAR samplers,
+    or a dict primitive -> (magFilter, minFilter, mipmapFilter)."""
     def mat(images, wrap=(B.WRAP_REPEAT, B.WRAP_REPEAT), **kw):
         m = _mat((0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), (0, 0, 0, 0), **kw)
         m["images"] = images
@@ -120,6 +130,9 @@ def detail_prims():
     card = KatPrim(scenes.plane(1.6, 1.6, 1, 1, uv_scale=1.5), scenes.translation(3.0, 1.2, -1.0) @ G.rotate(np.pi / 2, 0),
                    mat(_chain_images(64, 541, tint=(0.5, 1.0, 0.5), alpha=(0.2 + 0.6 * alpha).astype(np.float32)), alpha_mode=B.ALPHA_MASK, alpha_cutoff=0.5,
                        wrap=(B.WRAP_CLAMP, B.WRAP_MIRROR)))   # uv runs to 1.5: U clamped; V clamped too (wrapU is not the mirror mode)
+    if filters is not None:
+        for name, p in (("ground", ground), ("box", box), ("wall", wall), ("mover", mover), ("card", card)):
+            p.mat["filters"] = filters[name]
     return [ground, box, wall, mover], [card]
 
 
@@ -127,6 +140,8 @@ def prims(variant="base"):
     """The opaque primitives first, then the MASK / BLEND ones."""
     if variant == "detail":
         return detail_prims()
+    if variant == "filters":
+        return detail_prims(FILTERS)
     ground = KatPrim(scenes.plane(30, 30, 1, 1), scenes.translation(0, 0, -12) @ G.rotate(0.1, 2) @ SCALE,
                      _mat((200, 150, 100, 255), (150, 110, 240, 255), (0, 180, 60, 255), (210, 0, 0, 255), (30, 60, 90, 255),
                           base_color=(0.9, 0.8, 0.7, 1.0), emissive=(0.5, 0.25, 0.125), metallic=0.9, roughness=0.8, ao=0.9))
@@ -161,7 +176,7 @@ def build(r, env_faces, lut=None, with_meshes=True, variant="base"):
             m = p.mat
             if "images" in m:
                 m["image_ids"] = [r.load_image(m["images"][name], f) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
-                tex = [r.make_texture(i, *m["wrap"]) for i in m["image_ids"]]
+                tex = [r.make_texture(i, *m["wrap"], *m.get("filters", (LIN, LIN, LIN))) for i in m["image_ids"]]
             else:
                 tex = [r.make_texture(r.load_image(np.asarray(m[name], np.uint8).reshape(1, 1, 4), f)) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
             material = scenes.make_material(tex, base_color=m["base_color"], emissive=m["emissive"], metallic=m["metallic"],
@@ -170,7 +185,7 @@ def build(r, env_faces, lut=None, with_meshes=True, variant="base"):
     r.set_brdf_lut(reference_lut() if lut is None else lut)
     r.set_environment_map(env_faces)
     r.set_camera(position=CAMERA["position"], euler=CAMERA["euler"], near=CAMERA["near"], far=CAMERA["far"], fov_or_height=CAMERA["fov"])
-    r.set_lights(DETAIL_LIGHTS if variant == "detail" else [(p, i, False) for p, i in POINT_LIGHTS], directional_light())
+    r.set_lights(DETAIL_LIGHTS if variant != "base" else [(p, i, False) for p, i in POINT_LIGHTS], directional_light())
     return opaque, blended
 
 
@@ -248,7 +263,7 @@ def expected_hdr(r, W, H, margin, variant="base", built=None, details=None):
     n_casc = r.settings.directional_shadow_cascade_levels
     cascade_vps = [vps[i].T.astype(np.float64) for i in range(n_casc)]
     dl = directional_light()
-    if variant == "detail":
+    if variant != "base":
         cubes = point_light_cubes(r, DETAIL_LIGHTS, cam["position"])
         point_lights = [(l[0], l[1], cube) for l, cube in zip(DETAIL_LIGHTS, cubes)]
     else:
@@ -258,7 +273,7 @@ def expected_hdr(r, W, H, margin, variant="base", built=None, details=None):
                  prefiltered=[r.read_env_cube(2, l).astype(np.float64) for l in range(10)],
                  irradiance=r.read_env_cube(1).astype(np.float64), lut=reference_lut())
     opaque, blended = built if built is not None else prims(variant)
-    if variant == "detail":
+    if variant != "base":
         read_chains(r, opaque, blended)
     colour = np.zeros((H, W, 4))
     valid = np.ones((H, W), bool)

@@ -104,7 +104,7 @@ def _refusals(api):
         if rc == 0:
             api.destroy(ctx)
         return rc
-    out.append(("hdr output", create(hdr_output_enabled=1)))
+    out.append(("hdr output 2", create(hdr_output_enabled=2)))
     out.append(("msaa 2", create(msaa=2)))
     out.append(("5 cascades", create(directional_shadow_cascade_levels=5)))
     out.append(("cascade resolution 0", create(directional_shadow_map_resolution=0)))
@@ -115,7 +115,7 @@ def _refusals(api):
     return out
 
 
-EXPECTED_REFUSALS = [("hdr output", B.RDR_ERR_UNSUPPORTED), ("msaa 2", B.RDR_ERR_UNSUPPORTED), ("5 cascades", B.RDR_ERR_UNSUPPORTED),
+EXPECTED_REFUSALS = [("hdr output 2", B.RDR_ERR_INVALID), ("msaa 2", B.RDR_ERR_UNSUPPORTED), ("5 cascades", B.RDR_ERR_UNSUPPORTED),
                      ("cascade resolution 0", B.RDR_ERR_INVALID), ("point resolution 0", B.RDR_ERR_INVALID),
                      ("cascade resolution 65536", B.RDR_ERR_UNSUPPORTED), ("point resolution 16384", B.RDR_ERR_UNSUPPORTED),
                      ("1000 point shadow maps", B.RDR_ERR_UNSUPPORTED)]
@@ -123,13 +123,14 @@ EXPECTED_REFUSALS = [("hdr output", B.RDR_ERR_UNSUPPORTED), ("msaa 2", B.RDR_ERR
 
 def test_settings_the_checker_refuses(orc_capi):
     """RendererSettings values neither library implements are refused by rdr_create with a status, never silently ignored
-    (VulkanRenderer.h:44-59: hdrOutputEnabled, the shadow-map sizes and counts)."""
+    (VulkanRenderer.h:44-59: the shadow-map sizes and counts, the sample count)."""
     assert _refusals(orc_capi) == EXPECTED_REFUSALS
 
 
 def test_resources_the_checker_refuses(orc_capi):
-    """NEAREST sampler filters (VulkanRenderer.cpp:363-385) and image formats other than 8-bit RGB(A) (Image.h:5-14)
-    are refused with RDR_ERR_UNSUPPORTED; the 8-bit formats are accepted."""
+    """Image formats other than 8-bit RGB(A) (Image.h:5-14) are refused with RDR_ERR_UNSUPPORTED; the 8-bit formats and
+    every combination of the Sampler's filters (VulkanRenderer.cpp:363-385) are accepted, values outside the enums are
+    invalid."""
     _check_resource_refusals(orc_capi)
 
 
@@ -149,11 +150,17 @@ def _check_resource_refusals(api):
         rc = api.load_image(r._ctx, buf.ctypes.data_as(C.c_void_p), buf.size, 4, 4, fmt, 1, C.byref(out))
         assert rc == B.RDR_ERR_UNSUPPORTED, fmt
     img = r.load_image(px, B.FORMAT_R8G8B8A8_UNORM)
-    for filt in ((B.FILTER_NEAREST, B.FILTER_LINEAR, B.FILTER_LINEAR), (B.FILTER_LINEAR, B.FILTER_NEAREST, B.FILTER_LINEAR),
-                 (B.FILTER_LINEAR, B.FILTER_LINEAR, B.FILTER_NEAREST)):
+    for bits in range(8):
+        filt = [B.FILTER_NEAREST if bits >> k & 1 else B.FILTER_LINEAR for k in range(3)]
         s = B.Sampler(filt[0], filt[1], filt[2], B.WRAP_REPEAT, B.WRAP_REPEAT)
         out = C.c_uint32()
-        assert api.make_texture(r._ctx, img, C.byref(s), C.byref(out)) == B.RDR_ERR_UNSUPPORTED
+        assert api.make_texture(r._ctx, img, C.byref(s), C.byref(out)) == B.RDR_OK
+    for k in range(3):
+        filt = [B.FILTER_LINEAR] * 3
+        filt[k] = 2
+        s = B.Sampler(filt[0], filt[1], filt[2], B.WRAP_REPEAT, B.WRAP_REPEAT)
+        out = C.c_uint32()
+        assert api.make_texture(r._ctx, img, C.byref(s), C.byref(out)) == B.RDR_ERR_INVALID
     s = B.Sampler(B.FILTER_LINEAR, B.FILTER_LINEAR, B.FILTER_LINEAR, 7, B.WRAP_REPEAT)
     out = C.c_uint32()
     assert api.make_texture(r._ctx, img, C.byref(s), C.byref(out)) == B.RDR_ERR_INVALID

@@ -60,15 +60,19 @@ class Room:
         return parent, child, sphere
 
     def build_direct(self, r):
-        def textures(imgs, wrap=(B.WRAP_REPEAT, B.WRAP_REPEAT)):
+        def textures(imgs, wrap=(B.WRAP_REPEAT, B.WRAP_REPEAT), filters=(B.FILTER_LINEAR, B.FILTER_LINEAR, B.FILTER_LINEAR), mips=True):
             fmts = [B.FORMAT_R8G8B8A8_SRGB] + [B.FORMAT_R8G8B8A8_UNORM] * 4
-            return [r.make_texture(r.load_image(i, f), *wrap) for i, f in zip(imgs, fmts)]
+            return [r.make_texture(r.load_image(i, f, 0xFFFFFFFF if mips else 1), *wrap, *filters) for i, f in zip(imgs, fmts)]
 
         parent, child, sphere = self.graph()
         for n in (parent, sphere):
             n.recalculate_model()
-        r.add_mesh([scenes.upload_primitive(r, self.floor, scenes.make_material(textures(self.mat_floor)), B.UINT16)])
-        r.add_mesh([scenes.upload_primitive(r, self.box, scenes.make_material(textures(self.mat_box, (B.WRAP_MIRROR, B.WRAP_CLAMP)), ao=0.7), B.UINT16)],
+        # the floor's sampler: magFilter NEAREST, minFilter LINEAR without mip-mapping (9728 / 9729): an image of one level
+        floor_tex = textures(self.mat_floor, filters=(B.FILTER_NEAREST, B.FILTER_LINEAR, B.FILTER_NEAREST), mips=False)
+        r.add_mesh([scenes.upload_primitive(r, self.floor, scenes.make_material(floor_tex), B.UINT16)])
+        # the box's: magFilter LINEAR, minFilter NEAREST_MIPMAP_LINEAR (9729 / 9986)
+        box_tex = textures(self.mat_box, (B.WRAP_MIRROR, B.WRAP_CLAMP), filters=(B.FILTER_LINEAR, B.FILTER_NEAREST, B.FILTER_LINEAR))
+        r.add_mesh([scenes.upload_primitive(r, self.box, scenes.make_material(box_tex, ao=0.7), B.UINT16)],
                    model=np.float32(child.model.T))
         imgs = list(self.mat_sphere)
         imgs[1] = self.sphere_normal_jpeg
@@ -88,15 +92,15 @@ class Room:
     def write(self, path, glb=False, where="file"):
         w = GltfWriter()
 
-        def textures(imgs, name, wrap=(10497, 10497), jpeg_slot=None):
+        def textures(imgs, name, wrap=(10497, 10497), jpeg_slot=None, filters=(9729, 9987)):
             out = []
             for k, img in enumerate(imgs):
                 i, _ = w.image(img, f"{name}_{k}", where=where, fmt="JPEG" if k == jpeg_slot else "PNG")
-                out.append(w.texture(i, *wrap))
+                out.append(w.texture(i, *wrap, *filters))
             return out
 
-        m_floor = w.material(textures(self.mat_floor, "floor"))
-        m_box = w.material(textures(self.mat_box, "box", (33648, 33071)), ao=0.7)
+        m_floor = w.material(textures(self.mat_floor, "floor", filters=(9728, 9729)))
+        m_box = w.material(textures(self.mat_box, "box", (33648, 33071), filters=(9729, 9986)), ao=0.7)
         m_sph = w.material(textures(self.mat_sphere, "sphere", jpeg_slot=1), alpha_mode="MASK", alpha_cutoff=0.4, roughness=0.6)
         m_quad = w.material(None, base_color=(0.4, 0.6, 1.0, 0.5), emissive=(0.2, 0.1, 0.0), emissive_strength=3.0, metallic=0.0, roughness=0.8,
                             alpha_mode="BLEND")

@@ -358,3 +358,37 @@ def test_occlusion_and_metal_roughness_in_one_image(orc_capi, hip_capi, monkeypa
     hdr_o, hdr_h = ro.read_hdr(), rh.read_hdr()
     # the colour image to half precision nearly everywhere (a shadow edge may fall on the other side of a sample in a few pixels)
     assert np.mean(np.abs(hdr_o - hdr_h) > 4e-3 * np.abs(hdr_o) + 2e-3) < 1e-3
+
+
+@pytest.mark.parametrize("size", [(320, 180), (251, 141)])
+def test_float_output_frame(orc_capi, hip_capi, size):
+    """hdrOutputEnabled (VulkanRenderer.cpp:668-673): the frame arrives as RGBA16F, through the host destination, a
+    device destination and rdr_post_process; against the checker within the 8-bit output's bar (1/255), and nearly all
+    values within one binary16 step."""
+    import torch
+    W, H = size
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, hdr_output_enabled=1, **hp.small_settings(4))
+    scenes.small_scene(ro)
+    scenes.small_scene(rh)
+    out_o, avg_o = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    out_h, avg_h = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    assert out_o.dtype == np.float16 and out_h.dtype == np.float16 and out_h.shape == (H, W, 4)
+    a, b = out_o.astype(np.float64), out_h.astype(np.float64)
+    assert np.all(b[..., 3] == 1.0) and np.all(np.isfinite(b))
+    assert np.abs(a - b).max() <= 1.0 / 255.0
+    step = np.spacing(np.maximum(out_o, np.float16(2.0 ** -10))).astype(np.float64)
+    assert (np.abs(a - b) <= step).mean() > 0.995
+    assert abs(avg_o - avg_h) < 1e-3
+    # the same frame into device memory: written by the tonemap kernel itself (16-byte aligned destination) or copied
+    # (a destination that is not)
+    for offset in (0, 8):
+        buf = torch.zeros(W * H * 8 + 16, dtype=torch.uint8, device="cuda")
+        rh.render_frame(exposure_mode=1, temporal_luminance=0.5, device_ptr=buf.data_ptr() + offset)
+        rh.synchronize()
+        got = buf[offset:offset + W * H * 8].cpu().numpy().view(np.float16).reshape(H, W, 4)
+        assert np.array_equal(got.view(np.uint16), out_h.view(np.uint16)), offset
+    # the tail alone on the colour image of that frame
+    hdr = rh.read_hdr()
+    pp_h, _ = rh.post_process(hdr, rh.frame_stats().exposure)
+    assert np.array_equal(pp_h.view(np.uint16), out_h.view(np.uint16))
+    ro.close(); rh.close()

@@ -118,6 +118,43 @@ def test_tonemap_against_float64(orc_capi):
     assert np.allclose(r.read_log_luminance(), ll, atol=2e-6)
 
 
+def check_float_output(capi):
+    """hdrOutputEnabled (VulkanRenderer.h:45, VulkanRenderer.cpp:668-673): the output image has a float format, here
+    R16G16B16A16_SFLOAT, and receives tonemap.comp's values as they are: each channel is the float64 value rounded to
+    binary16 (within one step: float32 arithmetic), alpha is 1; quantised to 8 bits it is the UNORM output."""
+    W, H = 66, 47
+    rng = np.random.default_rng(6)
+    hdr = (rng.random((H, W, 4), dtype=np.float32) ** 2 * 6.0).astype(np.float16).astype(np.float32)
+    r = Renderer(capi, W, H, default_settings(hdr_output_enabled=1), keep_intermediates=True)  # bloom mip 0 is read back
+    out, avg = r.post_process(hdr, 0.7)
+    assert out.dtype == np.float16 and out.shape == (H, W, 4)
+    bloom0 = r.read_bloom(0).astype(np.float64)
+    col = hdr[..., :3].astype(np.float64)
+    v = tone(col * (1 - 0.04) + bloom0 * 0.04) / tone(11.2)
+    v = (1.0 - np.exp(-v * 2.0 ** 0.7)) ** (1.0 / 2.2)
+    got = out[..., :3].astype(np.float64)
+    step = np.spacing(v.astype(np.float16)).astype(np.float64)
+    assert np.all(np.abs(got - v) <= 0.75 * step + 1e-7), float(np.max(np.abs(got - v) / step))
+    assert (np.abs(got - v) <= 0.5 * step + 1e-7).mean() > 0.99   # rounded to nearest, but for float32 noise at ties
+    assert np.all(out[..., 3] == np.float16(1.0))
+    r8 = Renderer(capi, W, H, default_settings())
+    out8, avg8 = r8.post_process(hdr, 0.7)
+    assert avg == avg8
+    q = np.floor(got * 255.0 + 0.5)
+    # a binary16 step near 1 is an eighth of an 8-bit step: rounding twice moves a few percent of the bytes by one
+    assert np.abs(q - out8[..., :3]).max() <= 1 and (q != out8[..., :3]).mean() < 0.08
+    r.close(); r8.close()
+
+
+def test_float_output_image(orc_capi):
+    check_float_output(orc_capi)
+
+
+@pytest.mark.gpu
+def test_float_output_image_hip(hip_capi):
+    check_float_output(hip_capi)
+
+
 def test_average_luminance_is_the_centre_crop_mean(orc_capi):
     """VulkanRenderer.cpp:1165: a 256x256 window centred in the image is reduced to its mean."""
     W, H = 320, 300

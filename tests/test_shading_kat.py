@@ -59,15 +59,16 @@ def _segment_hits_box(P, light, prim, grow):
     return (tmin <= tmax) & (tmax >= 0.0) & (tmin <= 1.0)
 
 
-def check_detail(capi, msaa):
-    """Mip-mapped textures and shadowed point lights (the "detail" variant of tests/kat_scene.py)."""
+def check_detail(capi, msaa, variant="detail"):
+    """Mip-mapped textures and shadowed point lights (the "detail" variant of tests/kat_scene.py), or the same scene
+    with NEAREST filters in its Samplers (the "filters" variant)."""
     W, H = 240, 144
     r = _renderer(capi, W, H, msaa)
-    built = K.build(r, K.linear_environment(32), variant="detail")
+    built = K.build(r, K.linear_environment(32), variant=variant)
     r.render_frame(exposure_mode=2, exposure=0.0)
     got = r.read_hdr().astype(np.float64)
     det = {}
-    want, valid = K.expected_hdr(r, W, H, margin=0.02 if msaa == 1 else 1.0, variant="detail", built=built, details=det)
+    want, valid = K.expected_hdr(r, W, H, margin=0.02 if msaa == 1 else 1.0, variant=variant, built=built, details=det)
     opaque = built[0]
     on_geometry = det["prim"] >= 0
     n_frag = int((valid & on_geometry).sum())
@@ -111,8 +112,12 @@ def check_detail(capi, msaa):
             assert sel.sum() >= 200
         assert np.all(s_i[sel] == 1.0), f"light {i}: open ground under the light"
     # ---- and the colours: 2^-11 from each of up to two RGBA16F roundings, float32 arithmetic on top
-    _assert_close(got, want, valid, rtol=1.5e-3, atol=2e-4, what=f"pbr.frag with mip-mapped textures and shadowed point lights, msaa {msaa}")
-    return dict(fragments=n_frag, minified=n_minified, magnified=n_magnified, partly_shadowed=n_partly, fully_shadowed=n_fully)
+    _assert_close(got, want, valid, rtol=1.5e-3, atol=2e-4, what=f"pbr.frag, {variant} scene, msaa {msaa}")
+    per_prim = [int((valid & (det["prim"] == k)).sum()) for k in range(len(opaque))]
+    if variant == "filters":
+        # every filter combination of the scene keeps enough pinned fragments away from its texel and level boundaries
+        assert per_prim[0] >= 1500 and per_prim[1] >= 150 and per_prim[2] >= 100 and per_prim[3] >= 40, per_prim
+    return dict(fragments=n_frag, minified=n_minified, magnified=n_magnified, partly_shadowed=n_partly, fully_shadowed=n_fully, per_prim=per_prim)
 
 
 def check_sky(capi):
@@ -204,6 +209,18 @@ def test_environment_bakes_known_answers(orc_capi):
 @pytest.mark.parametrize("msaa", [1, 4])
 def test_mip_mapped_textures_and_shadowed_point_lights(orc_capi, msaa):
     print(check_detail(orc_capi, msaa))
+
+
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_nearest_sampler_filters(orc_capi, msaa):
+    """The Sampler's magFilter / minFilter / mipmapFilter (VulkanRenderer.cpp:363-385) by the Vulkan rules, in float64."""
+    print(check_detail(orc_capi, msaa, variant="filters"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_nearest_sampler_filters_hip(hip_capi, msaa):
+    print(check_detail(hip_capi, msaa, variant="filters"))
 
 
 @pytest.mark.gpu

@@ -41,3 +41,17 @@ def test_no_alloc_post_process_matches_post_process(hip_capi):
     assert hip_capi.post_process_noalloc(ctx._ctx, d_big.data_ptr(), 1, B.NOALLOC_MAX_PIXELS, 0.0, d_out.data_ptr(), d_avg.data_ptr(), None) == B.RDR_ERR_CAPACITY
     assert hip_capi.post_process_noalloc(ctx._ctx, None, 16, 16, 0.0, d_out.data_ptr(), d_avg.data_ptr(), None) == B.RDR_ERR_INVALID
     ctx.close()
+    # a context whose output image is RGBA16F (hdr_output_enabled): 8 bytes per pixel, the same values as its rdr_post_process
+    W, H, exposure = 321, 200, 0.25
+    ctx = Renderer(hip_capi, W, H, default_settings(hdr_output_enabled=1))
+    hdr = hp.random_hdr(W, H, seed=5).astype(np.float16)
+    want, want_avg = ctx.post_process(hdr.astype(np.float32), exposure)
+    d_hdr = torch.from_numpy(hdr.view(np.int16)).to(dev)
+    d_out = torch.zeros((H, W, 4), dtype=torch.float16, device=dev)
+    torch.cuda.synchronize()
+    rc = hip_capi.post_process_noalloc(ctx._ctx, d_hdr.data_ptr(), W, H, exposure, d_out.data_ptr(), d_avg.data_ptr(), None)
+    assert rc == B.RDR_OK, hip_capi.last_error(ctx._ctx)
+    ctx.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint16), want.view(np.uint16)) and float(d_avg.cpu()[0]) == want_avg
+    assert hip_capi.post_process_noalloc(ctx._ctx, d_hdr.data_ptr(), W, H, exposure, d_out.data_ptr() + 8, d_avg.data_ptr(), None) == B.RDR_ERR_INVALID
+    ctx.close()
