@@ -134,5 +134,6 @@ void launch_cube_quads(hipStream_t s, const uint32_t* bordered, void* dst, int r
 void launch_lut_quads(hipStream_t s, const uint32_t* src, void* dst, int w, int h);
 void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb);
 void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig);
-void launch_mip_blit(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int srgb, const float* srgb_decode,
-                     const float* unorm_decode, const float* thr);
+// levels 1 .. levels - 1 of an image whose level 0 (w x h texels) is at base + level_offset[0], each blitted from the one before
+void launch_mip_chain(hipStream_t s, uint32_t* base, const uint32_t* level_offset, uint32_t w, uint32_t h, uint32_t levels, int srgb,
+                      const float* srgb_decode, const float* unorm_decode, const float* thr);

@@ -11,6 +11,9 @@
 // CPU checker rather than speed: correctly rounded divide/sqrt, no
 // contraction, and the trigonometric values of the fixed sample angles come
 // from host tables.
+#include <algorithm>
+#include <cstring>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -121,12 +124,9 @@ __global__ void __launch_bounds__(256) k_bake_prefilter(DCube env, uint32_t* __r
 
 // vkCmdBlitImage(LINEAR) from one mip level to the next; sRGB images are
 // filtered in linear light. `thr` = 256 encode thresholds (linear value of code n + 0.5).
-__global__ void __launch_bounds__(256) k_mip_blit(const uint32_t* __restrict__ src, int sw, int sh, uint32_t* __restrict__ dst, int dw, int dh,
-                                                  int srgb, const float* __restrict__ srgb_decode, const float* __restrict__ unorm_decode,
-                                                  const float* __restrict__ thr) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (uint32_t)(dw * dh)) return;
-    const int x = (int)(i % (uint32_t)dw), y = (int)(i / (uint32_t)dw);
+// One destination texel (x, y):
+RDR_DEV uint32_t mip_blit_texel(const uint32_t* __restrict__ src, int sw, int sh, int x, int y, int dw, int dh, int srgb,
+                                const float* __restrict__ srgb_decode, const float* __restrict__ unorm_decode, const float* __restrict__ thr) {
     const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
     const float u = ((float)x + 0.5f) * scale_x - 0.5f, v = ((float)y + 0.5f) * scale_y - 0.5f;
     const float fu = floorf(u), fv = floorf(v);
@@ -157,7 +157,34 @@ __global__ void __launch_bounds__(256) k_mip_blit(const uint32_t* __restrict__ s
         } else code = float_to_unorm8(r);
         o |= code << (8 * k);
     }
-    dst[i] = o;
+    return o;
+}
+__global__ void __launch_bounds__(256) k_mip_blit(const uint32_t* __restrict__ src, int sw, int sh, uint32_t* __restrict__ dst, int dw, int dh,
+                                                  int srgb, const float* __restrict__ srgb_decode, const float* __restrict__ unorm_decode,
+                                                  const float* __restrict__ thr) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)(dw * dh)) return;
+    dst[i] = mip_blit_texel(src, sw, sh, (int)(i % (uint32_t)dw), (int)(i / (uint32_t)dw), dw, dh, srgb, srgb_decode, unorm_decode, thr);
+}
+// The small end of a chain in one launch: one block produces levels first + 1 .. last one after the other, each from
+// the level before it as stored (a block's own stores are visible to it after the barrier), so that an image costs
+// a handful of launches instead of one per level. Levels of at most MIP_TAIL_TEXELS texels are taken this way.
+#define MIP_TAIL_TEXELS 4096
+struct MipTail {
+    uint32_t n;  // levels to produce
+    uint32_t off[RDR_MAX_TEX_LEVELS];   // texel offset of the source level, then of every produced level
+    uint16_t w[RDR_MAX_TEX_LEVELS], h[RDR_MAX_TEX_LEVELS];
+};
+__global__ void __launch_bounds__(256) k_mip_blit_tail(uint32_t* __restrict__ base, const MipTail t, int srgb, const float* __restrict__ srgb_decode,
+                                                       const float* __restrict__ unorm_decode, const float* __restrict__ thr) {
+    for (uint32_t l = 1; l <= t.n; l++) {
+        const uint32_t* src = base + t.off[l - 1];
+        uint32_t* dst = base + t.off[l];
+        const int sw = t.w[l - 1], sh = t.h[l - 1], dw = t.w[l], dh = t.h[l];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(dw * dh); i += 256u)
+            dst[i] = mip_blit_texel(src, sw, sh, (int)(i % (uint32_t)dw), (int)(i / (uint32_t)dw), dw, dh, srgb, srgb_decode, unorm_decode, thr);
+        __syncthreads();
+    }
 }
 
 // ---- precompute steps with no counterpart in the reference (it receives six decoded faces and loads its BRDF table
@@ -346,7 +373,18 @@ void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int 
 void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig) {
     hipLaunchKernelGGL(k_bake_prefilter, dim3((6u * res * res + 255) / 256), dim3(256), 0, s, env, dst, res, roughness, trig);
 }
-void launch_mip_blit(hipStream_t s, const uint32_t* src, int sw, int sh, uint32_t* dst, int dw, int dh, int srgb, const float* srgb_decode,
-                     const float* unorm_decode, const float* thr) {
-    hipLaunchKernelGGL(k_mip_blit, dim3((dw * dh + 255) / 256), dim3(256), 0, s, src, sw, sh, dst, dw, dh, srgb, srgb_decode, unorm_decode, thr);
+void launch_mip_chain(hipStream_t s, uint32_t* base, const uint32_t* level_offset, uint32_t w, uint32_t h, uint32_t levels, int srgb,
+                      const float* srgb_decode, const float* unorm_decode, const float* thr) {
+    auto dim = [](uint32_t v, uint32_t l) { return (int)std::max(1u, v >> l); };
+    uint32_t l = 1;
+    // the large levels one launch each, until the source level is small enough for one block
+    for (; l < levels && (size_t)dim(w, l - 1) * dim(h, l - 1) > MIP_TAIL_TEXELS; l++)
+        hipLaunchKernelGGL(k_mip_blit, dim3((dim(w, l) * dim(h, l) + 255) / 256), dim3(256), 0, s, base + level_offset[l - 1], dim(w, l - 1), dim(h, l - 1),
+                           base + level_offset[l], dim(w, l), dim(h, l), srgb, srgb_decode, unorm_decode, thr);
+    if (l >= levels) return;
+    MipTail t;
+    memset(&t, 0, sizeof t);
+    t.n = levels - l;
+    for (uint32_t k = 0; k <= t.n; k++) { t.off[k] = level_offset[l - 1 + k]; t.w[k] = (uint16_t)dim(w, l - 1 + k); t.h[k] = (uint16_t)dim(h, l - 1 + k); }
+    hipLaunchKernelGGL(k_mip_blit_tail, dim3(1), dim3(256), 0, s, base, t, srgb, srgb_decode, unorm_decode, thr);
 }

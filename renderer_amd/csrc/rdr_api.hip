@@ -603,12 +603,7 @@ int create_image(rdr_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h, bool s
     HIP_TRY(img.pixels.ensure(texels * 4 + 16));  // the shading kernels read texel pairs: one texel of slack after the last level
     HIP_TRY(hipMemcpyAsync(img.pixels.p, rgba, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream));
     const float* tables = c->d_tables.as<float>();
-    for (uint32_t l = 1; l < levels; l++) {
-        uint32_t* base = img.pixels.as<uint32_t>();
-        launch_mip_blit(c->stream, base + img.level_offset[l - 1], (int)std::max(1u, w >> (l - 1)), (int)std::max(1u, h >> (l - 1)),
-                        base + img.level_offset[l], (int)std::max(1u, w >> l), (int)std::max(1u, h >> l), srgb ? 1 : 0, tables, tables + 256,
-                        tables + 512);
-    }
+    launch_mip_chain(c->stream, img.pixels.as<uint32_t>(), img.level_offset, w, h, levels, srgb ? 1 : 0, tables, tables + 256, tables + 512);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     c->images.push_back(img);
