@@ -56,7 +56,8 @@ typedef struct rdr_settings {
     uint32_t msaa;                             /* 1 or 4; default 4 */
 } rdr_settings;
 
-/* Image formats: Renderer/Image.h:5-14 (same order, same values). */
+/* Image formats: Renderer/Image.h:5-14 (same order, same values). Input texels are tightly packed in the named
+ * format (3, 4, 6, 8, 12 or 16 bytes each). The three-component formats read alpha as 1. */
 enum rdr_image_format {
     RDR_FORMAT_R8G8B8_UNORM = 0,
     RDR_FORMAT_R8G8B8_SRGB = 1,
@@ -251,7 +252,8 @@ const char* rdr_backend_name(void);
 /* VulkanRenderer::loadBuffer (VulkanRenderer.cpp:273-299). */
 int rdr_load_buffer(rdr_ctx* ctx, const void* ptr, size_t size, uint32_t* out_id);
 /* VulkanRenderer::loadImage (VulkanRenderer.cpp:305-361): uploads level 0 and
- * builds the mip chain by successive linear blits. */
+ * builds the mip chain by successive linear blits (sRGB formats filter in linear
+ * light; the 16-bit float formats round every level to binary16). */
 int rdr_load_image(rdr_ctx* ctx, const void* ptr, size_t size, uint32_t width, uint32_t height,
                    int format, uint32_t max_mip_levels, uint32_t* out_id);
 /* VulkanRenderer::makeTexture (VulkanRenderer.cpp:363-385). */
@@ -381,7 +383,8 @@ int rdr_read_cascades(rdr_ctx* ctx, float* out_viewproj_4x16, float* out_depth_4
 int rdr_read_primitive_positions(rdr_ctx* ctx, uint32_t mesh_id, uint32_t primitive, float* out_xyz, uint32_t* out_count);
 /* the installed BRDF table as RGBA8, row 0 first; out may be NULL to query the size. */
 int rdr_read_brdf_lut(rdr_ctx* ctx, uint8_t* out, uint32_t* out_w, uint32_t* out_h);
-/* mip `level` of image `image` as stored (RGBA8), for mip-chain parity. */
+/* mip `level` of image `image` as stored, for mip-chain parity: RGBA8 (4 bytes per texel), or for an image of one of
+ * the SFLOAT formats one float[4] per texel (16 bytes; the 16-bit formats hold values representable in binary16). */
 int rdr_read_image_level(rdr_ctx* ctx, uint32_t image, uint32_t level, uint8_t* out, uint32_t* out_w, uint32_t* out_h);
 
 /* ---- stand-alone post-process entry point ------------------------------ */

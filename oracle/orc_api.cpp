@@ -332,21 +332,43 @@ int orc_load_buffer(rdr_ctx* c, const void* ptr, size_t size, uint32_t* out_id) 
 int orc_load_image(rdr_ctx* c, const void* ptr, size_t size, uint32_t w, uint32_t h, int format, uint32_t max_mips, uint32_t* out_id) {
     if (!c || !ptr || !out_id || w == 0 || h == 0) return fail(c, RDR_ERR_INVALID, "load_image: bad argument");
     int ch;
-    bool srgb;
+    bool srgb = false;
+    int float_bytes = 0;  // bytes per component of an SFLOAT format (Renderer/Image.h:9-12), 0 for the 8-bit ones
     switch (format) {
-        case RDR_FORMAT_R8G8B8_UNORM: ch = 3; srgb = false; break;
+        case RDR_FORMAT_R8G8B8_UNORM: ch = 3; break;
         case RDR_FORMAT_R8G8B8_SRGB: ch = 3; srgb = true; break;
-        case RDR_FORMAT_R8G8B8A8_UNORM: ch = 4; srgb = false; break;
+        case RDR_FORMAT_R8G8B8A8_UNORM: ch = 4; break;
         case RDR_FORMAT_R8G8B8A8_SRGB: ch = 4; srgb = true; break;
-        default: return fail(c, RDR_ERR_UNSUPPORTED, "load_image: only 8-bit formats are supported");
+        case RDR_FORMAT_R16G16B16_SFLOAT: ch = 3; float_bytes = 2; break;
+        case RDR_FORMAT_R16G16B16A16_SFLOAT: ch = 4; float_bytes = 2; break;
+        case RDR_FORMAT_R32G32B32_SFLOAT: ch = 3; float_bytes = 4; break;
+        case RDR_FORMAT_R32G32B32A32_SFLOAT: ch = 4; float_bytes = 4; break;
+        default: return fail(c, RDR_ERR_INVALID, "load_image: unknown format");
     }
-    if (size < (size_t)w * h * ch) return fail(c, RDR_ERR_INVALID, "load_image: size too small");
+    if (size < (size_t)w * h * ch * (float_bytes ? float_bytes : 1)) return fail(c, RDR_ERR_INVALID, "load_image: size too small");
+    if (w > 32768u || h > 32768u) return fail(c, RDR_ERR_UNSUPPORTED, "load_image: images larger than 32768 texels on a side are not supported");
     Image img; img.w = w; img.h = h; img.srgb = srgb;
-    img.mips.emplace_back((size_t)w * h * 4);
     const uint8_t* s = (const uint8_t*)ptr;
-    for (size_t i = 0; i < (size_t)w * h; i++) {
-        for (int k = 0; k < 3; k++) img.mips[0][i * 4 + k] = s[i * ch + k];
-        img.mips[0][i * 4 + 3] = ch == 4 ? s[i * ch + 3] : 255;
+    if (float_bytes) {
+        // one float[4] per texel; a component the format lacks reads as 1 (alpha of the three-component formats)
+        img.is_float = true; img.half_texels = float_bytes == 2;
+        img.mips.emplace_back((size_t)w * h * 16);
+        float* f = reinterpret_cast<float*>(img.mips[0].data());
+        for (size_t i = 0; i < (size_t)w * h; i++)
+            for (int k = 0; k < 4; k++) {
+                float v = 1.0f;
+                if (k < ch) {
+                    if (float_bytes == 2) { uint16_t hb; std::memcpy(&hb, s + (i * ch + k) * 2, 2); v = half_to_float(hb); }
+                    else std::memcpy(&v, s + (i * ch + k) * 4, 4);
+                }
+                f[i * 4 + k] = v;
+            }
+    } else {
+        img.mips.emplace_back((size_t)w * h * 4);
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            for (int k = 0; k < 3; k++) img.mips[0][i * 4 + k] = s[i * ch + k];
+            img.mips[0][i * 4 + 3] = ch == 4 ? s[i * ch + 3] : 255;
+        }
     }
     build_mips(*c, img, max_mips);
     c->images.push_back(std::move(img));

@@ -44,15 +44,40 @@ static void blit_level(const Ctx& c, const std::vector<uint8_t>& src, int sw, in
         }
 }
 
+// The same blit for an SFLOAT image: texels filtered as they are, rounded to binary16 where the image stores that.
+static void blit_level_float(const std::vector<uint8_t>& src_bytes, int sw, int sh, std::vector<uint8_t>& dst_bytes, int dw, int dh, bool to_half) {
+    dst_bytes.assign((size_t)dw * dh * 16, 0);
+    const float* src = reinterpret_cast<const float*>(src_bytes.data());
+    float* dst = reinterpret_cast<float*>(dst_bytes.data());
+    const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const float u = ((float)x + 0.5f) * scale_x - 0.5f, v = ((float)y + 0.5f) * scale_y - 0.5f;
+            const float fu = std::floor(u), fv = std::floor(v);
+            const float a = u - fu, b = v - fv;
+            const int i0 = std::min(std::max((int)fu, 0), sw - 1), i1 = std::min(std::max((int)fu + 1, 0), sw - 1);
+            const int j0 = std::min(std::max((int)fv, 0), sh - 1), j1 = std::min(std::max((int)fv + 1, 0), sh - 1);
+            for (int k = 0; k < 4; k++) {
+                const float t00 = src[((size_t)j0 * sw + i0) * 4 + k], t10 = src[((size_t)j0 * sw + i1) * 4 + k];
+                const float t01 = src[((size_t)j1 * sw + i0) * 4 + k], t11 = src[((size_t)j1 * sw + i1) * 4 + k];
+                const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
+                const float r = (1.0f - b) * top + b * bot;
+                dst[((size_t)y * dw + x) * 4 + k] = to_half ? quantize_half(r) : r;
+            }
+        }
+}
+
 // Renderer/VulkanRenderer.cpp:311-315: levels = floor(log2(max(w,h))) + 1, capped by maxMipLevels
 void build_mips(Ctx& c, Image& img, uint32_t max_levels) {
     uint32_t levels = 1, m = std::max(img.w, img.h);
     if (m > 1) levels = (uint32_t)std::floor(std::log2((double)m)) + 1;
     levels = std::max(1u, std::min(levels, max_levels));
     img.mips.resize(levels);
-    for (uint32_t l = 1; l < levels; l++)
-        blit_level(c, img.mips[l - 1], (int)mip_dim(img.w, l - 1), (int)mip_dim(img.h, l - 1), img.mips[l], (int)mip_dim(img.w, l),
-                   (int)mip_dim(img.h, l), img.srgb);
+    for (uint32_t l = 1; l < levels; l++) {
+        const int sw = (int)mip_dim(img.w, l - 1), sh = (int)mip_dim(img.h, l - 1), dw = (int)mip_dim(img.w, l), dh = (int)mip_dim(img.h, l);
+        if (img.is_float) blit_level_float(img.mips[l - 1], sw, sh, img.mips[l], dw, dh, img.half_texels);
+        else blit_level(c, img.mips[l - 1], sw, sh, img.mips[l], dw, dh, img.srgb);
+    }
 }
 
 static inline int wrap_index(int i, int n, uint32_t mode) {
@@ -73,6 +98,16 @@ static void bilinear(const Ctx& c, const Image& img, const rdr_sampler& s, uint3
     const float a = tu - fu, b = tv - fv;
     const int i0 = wrap_index((int)fu, w, s.wrap_u), i1 = wrap_index((int)fu + 1, w, s.wrap_u);
     const int j0 = wrap_index((int)fv, h, s.wrap_v), j1 = wrap_index((int)fv + 1, h, s.wrap_v);
+    if (img.is_float) {
+        const float* fx = reinterpret_cast<const float*>(px.data());
+        for (int k = 0; k < 4; k++) {
+            const float t00 = fx[((size_t)j0 * w + i0) * 4 + k], t10 = fx[((size_t)j0 * w + i1) * 4 + k];
+            const float t01 = fx[((size_t)j1 * w + i0) * 4 + k], t11 = fx[((size_t)j1 * w + i1) * 4 + k];
+            const float top = (1.0f - a) * t00 + a * t10, bot = (1.0f - a) * t01 + a * t11;
+            out[k] = (1.0f - b) * top + b * bot;
+        }
+        return;
+    }
     for (int k = 0; k < 4; k++) {
         const uint8_t q00 = px[((size_t)j0 * w + i0) * 4 + k], q10 = px[((size_t)j0 * w + i1) * 4 + k];
         const uint8_t q01 = px[((size_t)j1 * w + i0) * 4 + k], q11 = px[((size_t)j1 * w + i1) * 4 + k];
@@ -90,6 +125,11 @@ static void nearest(const Ctx& c, const Image& img, const rdr_sampler& s, uint32
     const int w = (int)mip_dim(img.w, level), h = (int)mip_dim(img.h, level);
     const std::vector<uint8_t>& px = img.mips[level];
     const int i = wrap_index((int)std::floor(u * (float)w), w, s.wrap_u), j = wrap_index((int)std::floor(v * (float)h), h, s.wrap_v);
+    if (img.is_float) {
+        const float* fx = reinterpret_cast<const float*>(px.data());
+        for (int k = 0; k < 4; k++) out[k] = fx[((size_t)j * w + i) * 4 + k];
+        return;
+    }
     for (int k = 0; k < 4; k++) {
         const uint8_t q = px[((size_t)j * w + i) * 4 + k];
         out[k] = (img.srgb && k < 3) ? c.srgb.decode[q] : (float)q / 255.0f;

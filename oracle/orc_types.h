@@ -20,7 +20,9 @@ namespace orc {
 struct Image {
     uint32_t w = 0, h = 0;
     bool srgb = false;
-    std::vector<std::vector<uint8_t>> mips;  // RGBA8 per level
+    bool is_float = false;     // an SFLOAT format of Renderer/Image.h:9-12: a level holds one float[4] per texel instead of RGBA8
+    bool half_texels = false;  // ... stored as binary16 in the reference's image: every level holds values rounded to it
+    std::vector<std::vector<uint8_t>> mips;  // per level: RGBA8, or the bytes of float[4] texels
 };
 struct Texture {
     uint32_t image;

@@ -14,6 +14,7 @@ INVALID_ID = 0xFFFFFFFF
 
 # enum rdr_image_format (Renderer/Image.h:5-14)
 FORMAT_R8G8B8_UNORM, FORMAT_R8G8B8_SRGB, FORMAT_R8G8B8A8_UNORM, FORMAT_R8G8B8A8_SRGB = 0, 1, 2, 3
+FORMAT_R16G16B16_SFLOAT, FORMAT_R16G16B16A16_SFLOAT, FORMAT_R32G32B32_SFLOAT, FORMAT_R32G32B32A32_SFLOAT = 4, 5, 6, 7
 # enum rdr_value_type / rdr_container_type (Renderer/Mesh.h:12-52)
 INT8, INT16, INT32, INT64, UINT8, UINT16, UINT32, UINT64, HALF, FLOAT, DOUBLE = range(11)
 SCALAR, VEC2, VEC3, VEC4 = range(4)

@@ -112,11 +112,16 @@ class Renderer:
         return out.value
 
     def load_image(self, pixels, fmt, max_mip_levels=0xFFFFFFFF):
-        a = np.ascontiguousarray(pixels, dtype=np.uint8)
+        """pixels [h, w, channels]: uint8 for the 8-bit formats, float16 / float32 for the SFLOAT ones (Image.h:5-14)."""
+        dtype = {B.FORMAT_R16G16B16_SFLOAT: np.float16, B.FORMAT_R16G16B16A16_SFLOAT: np.float16, B.FORMAT_R32G32B32_SFLOAT: np.float32,
+                 B.FORMAT_R32G32B32A32_SFLOAT: np.float32}.get(int(fmt), np.uint8)
+        a = np.ascontiguousarray(pixels, dtype=dtype)
         h, w = a.shape[0], a.shape[1]
+        self._image_is_float = getattr(self, "_image_is_float", {})
         out = C.c_uint32()
-        self._check(self.api.load_image(self._ctx, a.ctypes.data_as(B._VP), a.size, w, h, int(fmt), int(max_mip_levels),
+        self._check(self.api.load_image(self._ctx, a.ctypes.data_as(B._VP), a.nbytes, w, h, int(fmt), int(max_mip_levels),
                                         C.byref(out)), "load_image")
+        self._image_is_float[out.value] = dtype != np.uint8
         return out.value
 
     def make_texture(self, image, wrap_u=B.WRAP_REPEAT, wrap_v=B.WRAP_REPEAT, mag_filter=B.FILTER_LINEAR, min_filter=B.FILTER_LINEAR,
@@ -327,8 +332,9 @@ class Renderer:
     def read_image_level(self, image, level):
         w, h = C.c_uint32(), C.c_uint32()
         self._check(self.api.read_image_level(self._ctx, image, level, None, C.byref(w), C.byref(h)), "read_image_level")
-        a = np.empty((h.value, w.value, 4), np.uint8)
-        self._check(self.api.read_image_level(self._ctx, image, level, B.u8ptr(a), C.byref(w), C.byref(h)), "read_image_level")
+        # as stored: RGBA8, or one float32[4] per texel for an image of an SFLOAT format
+        a = np.empty((h.value, w.value, 4), np.float32 if getattr(self, "_image_is_float", {}).get(image) else np.uint8)
+        self._check(self.api.read_image_level(self._ctx, image, level, a.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(w), C.byref(h)), "read_image_level")
         return a
 
 

@@ -417,9 +417,10 @@ RDR_DEV void tex_taps(const DTexDesc& t, const DTexture* __restrict__ table, flo
     tex_level_taps(t, table, l0, u, v, false, o.lv[0]);
     if (o.two) tex_level_taps(t, table, l1, u, v, false, o.lv[1]);
 }
-// texture geometry = size, level count, level-offset rule, wrap modes and filters (not the sRGB bit, not the table index)
+// texture geometry = size, level count, level-offset rule, wrap modes, filters and texel type (not the sRGB bit, not the
+// table index)
 RDR_DEV bool tex_same_geometry(const DTexDesc& x, const DTexDesc& y) {
-    return (int)(x.wh == y.wh) & (int)(((x.info ^ y.info) & (31u | (0x1FEu << 5))) == 0u);
+    return (int)(x.wh == y.wh) & (int)(((x.info ^ y.info) & (31u | (0x3FEu << 5))) == 0u);
 }
 // Bilinear filter of four raw RGBA8 texels. sRGB channels go through the decode table before filtering; UNORM
 // channels are filtered as bytes and scaled by 1/255 once afterwards.
@@ -450,8 +451,22 @@ RDR_DEV void tex_filter(const float* srgb, bool is_srgb, uint32_t q00, uint32_t 
         out[c] = (c == 3 || !is_srgb) ? v * RDR_INV255 : v;
     }
 }
-template <int MASK>
+// FLOAT_TEXELS: the kernel is the build that also samples SFLOAT images (launched only when a context holds one, so that
+// the common build keeps the register count it has without that branch).
+template <int MASK, bool FLOAT_TEXELS = false>
 RDR_DEV void tex_fetch_level(const float* srgb, const DTexDesc& t, const TexLevelTaps& k, float out[4]) {
+    if (FLOAT_TEXELS && ((t.info >> 5) & RDR_TEXD_FLOAT)) {
+        // an SFLOAT image (Image.h:9-12): one float4 per texel, filtered as it is (no decode, no scale)
+        const RDR_GLOBAL float* fx = as_global((const float*)t.base);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (!(MASK & (1 << c))) continue;
+            const float c00 = fx[4u * k.o00 + c], c10 = fx[4u * k.o10 + c], c01 = fx[4u * k.o01 + c], c11 = fx[4u * k.o11 + c];
+            const float top = fmaf(k.a, c10 - c00, c00), bot = fmaf(k.a, c11 - c01, c01);
+            out[c] = fmaf(k.b, bot - top, top);
+        }
+        return;
+    }
     const RDR_GLOBAL uint32_t* px = as_global((const uint32_t*)t.base);
     // the two texels of a row are neighbours in memory unless the footprint wraps around the edge
     uint32_t q00, q10, q01, q11;
@@ -460,12 +475,12 @@ RDR_DEV void tex_fetch_level(const float* srgb, const DTexDesc& t, const TexLeve
     if (k.o10 != k.o00 + 1u) { q10 = px[k.o10]; q11 = px[k.o11]; }
     tex_filter<MASK>(srgb, ((t.info >> 5) & RDR_TEXD_SRGB) != 0u, q00, q10, q01, q11, k.a, k.b, out);
 }
-template <int MASK>
+template <int MASK, bool FLOAT_TEXELS = false>
 RDR_DEV void tex_fetch(const float* srgb, const DTexDesc& t, const TexTaps& k, float out[4]) {
-    tex_fetch_level<MASK>(srgb, t, k.lv[0], out);
+    tex_fetch_level<MASK, FLOAT_TEXELS>(srgb, t, k.lv[0], out);
     if (k.two) {
         float c1[4];
-        tex_fetch_level<MASK>(srgb, t, k.lv[1], c1);
+        tex_fetch_level<MASK, FLOAT_TEXELS>(srgb, t, k.lv[1], c1);
 #pragma unroll
         for (int c = 0; c < 4; c++)
             if (MASK & (1 << c)) out[c] = fmaf(k.f, c1[c] - out[c], out[c]);

@@ -100,7 +100,9 @@ uint32_t shade_frags_blocks_per_cu();  // blocks of k_shade_frags that fit a com
 FragLists make_frag_lists(uint32_t W, uint32_t H, int samples, void* frag_recs, void* frag_cols, uint32_t* pixel_state, uint32_t* tile_first,
                           uint32_t* list_count, uint32_t* list_claim);
 void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const uint32_t* vis, const FragLists& L);
-void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks);
+// float_texels: some image of the context has an SFLOAT format (the build of the kernel that can sample those)
+void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks,
+                        bool float_texels);
 // the visibility image rebuilt from the lists (frames whose rasteriser built the lists do not store it)
 void launch_vis_from_lists(hipStream_t s, int samples, const FragLists& L, uint32_t W, uint32_t H, uint32_t* vis);
 void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const FragLists& L, void* hdr, void* samples_out, const uint32_t* blend_start,
@@ -111,7 +113,7 @@ void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const Fra
 #define RDR_BLEND_SHADE_BLOCKS 2048u
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t tile0, uint32_t n_tiles, void* color,
-                         void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity);
+                         void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity, bool float_texels);
 // dry run of the collect pass over all tiles: tile_slots[tile] = list slots the tile would take (0 for tiles without blended triangles; zero the array first)
 void launch_blend_count(hipStream_t s, int samples, const DView* view, const DTriRec* recs, const uint32_t* sorted_vals, const uint32_t* tile_start,
                         const uint32_t* tile_end, uint32_t n_tiles, uint32_t* tile_slots);
@@ -134,6 +136,8 @@ void launch_cube_quads(hipStream_t s, const uint32_t* bordered, void* dst, int r
 void launch_lut_quads(hipStream_t s, const uint32_t* src, void* dst, int w, int h);
 void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int res, const IrradianceTables& tb);
 void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig);
+// the same for an image of float4 texels; to_half: every level rounded to binary16
+void launch_mip_chain_f32(hipStream_t s, float* base, const uint32_t* level_offset, uint32_t w, uint32_t h, uint32_t levels, bool to_half);
 // levels 1 .. levels - 1 of an image whose level 0 (w x h texels) is at base + level_offset[0], each blitted from the one before
 void launch_mip_chain(hipStream_t s, uint32_t* base, const uint32_t* level_offset, uint32_t w, uint32_t h, uint32_t levels, int srgb,
                       const float* srgb_decode, const float* unorm_decode, const float* thr);

@@ -338,6 +338,31 @@ __global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ dst, float
     if (i < n) dst[i] = v;
 }
 
+// The same blit for the SFLOAT formats (one float4 per texel): filtered as it is; `to_half`: the image stores binary16
+// (R16G16B16(A16)_SFLOAT), so every level is rounded to it as the blit's store would.
+__global__ void __launch_bounds__(256) k_mip_blit_f32(const float4* __restrict__ src, int sw, int sh, float4* __restrict__ dst, int dw, int dh, int to_half) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)(dw * dh)) return;
+    const int x = (int)(i % (uint32_t)dw), y = (int)(i / (uint32_t)dw);
+    const float scale_x = (float)sw / (float)dw, scale_y = (float)sh / (float)dh;
+    const float u = ((float)x + 0.5f) * scale_x - 0.5f, v = ((float)y + 0.5f) * scale_y - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const int i0 = min(max((int)fu, 0), sw - 1), i1 = min(max((int)fu + 1, 0), sw - 1);
+    const int j0 = min(max((int)fv, 0), sh - 1), j1 = min(max((int)fv + 1, 0), sh - 1);
+    const float4 q00 = src[j0 * sw + i0], q10 = src[j0 * sw + i1], q01 = src[j1 * sw + i0], q11 = src[j1 * sw + i1];
+    const float t00[4] = {q00.x, q00.y, q00.z, q00.w}, t10[4] = {q10.x, q10.y, q10.z, q10.w};
+    const float t01[4] = {q01.x, q01.y, q01.z, q01.w}, t11[4] = {q11.x, q11.y, q11.z, q11.w};
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float top = (1.0f - a) * t00[k] + a * t10[k], bot = (1.0f - a) * t01[k] + a * t11[k];
+        r[k] = (1.0f - b) * top + b * bot;
+        if (to_half) r[k] = quantize_half(r[k]);
+    }
+    dst[i] = make_float4(r[0], r[1], r[2], r[3]);
+}
+
 }  // namespace
 
 void launch_equirect_to_cube(hipStream_t s, const void* pano_rgba32f, int w, int h, uint32_t* dst, int res) {
@@ -372,6 +397,13 @@ void launch_bake_irradiance(hipStream_t s, const DCube& env, uint32_t* dst, int 
 }
 void launch_bake_prefilter(hipStream_t s, const DCube& env, uint32_t* dst, int res, float roughness, const float* trig) {
     hipLaunchKernelGGL(k_bake_prefilter, dim3((6u * res * res + 255) / 256), dim3(256), 0, s, env, dst, res, roughness, trig);
+}
+void launch_mip_chain_f32(hipStream_t s, float* base, const uint32_t* level_offset, uint32_t w, uint32_t h, uint32_t levels, bool to_half) {
+    auto dim = [](uint32_t v, uint32_t l) { return (int)std::max(1u, v >> l); };
+    float4* texels = (float4*)base;
+    for (uint32_t l = 1; l < levels; l++)
+        hipLaunchKernelGGL(k_mip_blit_f32, dim3((dim(w, l) * dim(h, l) + 255) / 256), dim3(256), 0, s, texels + level_offset[l - 1], dim(w, l - 1),
+                           dim(h, l - 1), texels + level_offset[l], dim(w, l), dim(h, l), to_half ? 1 : 0);
 }
 void launch_mip_chain(hipStream_t s, uint32_t* base, const uint32_t* level_offset, uint32_t w, uint32_t h, uint32_t levels, int srgb,
                       const float* srgb_decode, const float* unorm_decode, const float* thr) {

@@ -250,7 +250,7 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
         const DTexture& t = fr.textures[ti];
         const bool pow2sq = t.w == t.h && (t.w & (t.w - 1u)) == 0u && (t.levels == 1u || (1u << (t.levels - 1u)) == t.w);
         const uint32_t flags = (t.flags & 1u) | (pow2sq ? RDR_TEXD_POW2_SQUARE : 0u) | (((t.flags >> 4) & 3u) << 2) | (((t.flags >> 8) & 3u) << 4) |
-                               (((t.flags >> 12) & 7u) << RDR_TEXD_NEAREST_SHIFT);
+                               (((t.flags >> 12) & 7u) << RDR_TEXD_NEAREST_SHIFT) | (((t.flags >> 16) & 1u) ? RDR_TEXD_FLOAT : 0u);
         o.tex[k].base = t.base;
         o.tex[k].wh = t.w | (t.h << 16);
         o.tex[k].info = t.levels | (flags << 5) | (ti << 16);
@@ -266,7 +266,7 @@ RDR_DEV void shade_tri_setup(const DFrame& fr, const DDraw& d, uint32_t tri, DSh
 // interpolated frame vectors are not needed while the textures are fetched and filtered - the part of the function
 // that takes every register there is - and wait there meanwhile (otherwise the compiler spills them, and more, to
 // scratch memory: stores that go out to HBM).
-template <bool MASKED, bool PARK>
+template <bool MASKED, bool PARK, bool FLOAT_TEXELS = false>
 RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ lights, const float* srgb, const DShadeTri& T, const DShadeTri& M,
                             int px, int py, float out[4], float* park) {
     // Multiply-add pairs may fuse in this function: what must round as in the CPU checker is written with explicit
@@ -338,8 +338,10 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         for (int k = 0; k < 5; k++) td[k] = M.tex[k];
         TexTaps taps0;
         tex_taps(td[0], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps0);
+        // (float texels are part of the geometry: a material with an SFLOAT image takes the one-by-one path)
         const bool uniform_taps = (int)tex_pairs_adjacent(taps0) & (int)tex_same_geometry(td[1], td[0]) & (int)tex_same_geometry(td[2], td[0]) &
-                                  (int)tex_same_geometry(td[3], td[0]) & (int)tex_same_geometry(td[4], td[0]);
+                                  (int)tex_same_geometry(td[3], td[0]) & (int)tex_same_geometry(td[4], td[0]) &
+                                  (int)(!FLOAT_TEXELS || ((td[0].info >> 5) & RDR_TEXD_FLOAT) == 0u);
         if (__all(uniform_taps)) {
             // RDR_TEX_SERIAL: one texture at a time (five memory round trips, few registers: the kernel then fits more
             // waves per SIMD, which hide the round trips); otherwise all loads in flight together (one round trip, forty
@@ -387,14 +389,14 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
             RDR_TEX_FENCE();
         } else {
             TexTaps taps;
-            tex_fetch<15>(srgb, td[0], taps0, t);
+            tex_fetch<15, FLOAT_TEXELS>(srgb, td[0], taps0, t);
 #pragma unroll
             for (int k = 0; k < 4; k++) albedo[k] = t[k] * mt.base_color[k];
             if (MASKED && mt.alpha_mode == 1 && albedo[3] < mt.alpha_cutoff) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
 #define RDR_SAMPLE_SLOT(slot, mask)                                                                              \
             taps = taps0;                                                                                        \
             if (!__all(tex_same_geometry(td[slot], td[0]))) tex_taps(td[slot], fr.textures, u0, v0, dudx, dvdx, dudy, dvdy, taps); \
-            tex_fetch<mask>(srgb, td[slot], taps, t);
+            tex_fetch<mask, FLOAT_TEXELS>(srgb, td[slot], taps, t);
             RDR_SAMPLE_SLOT(2, 6)
             metallic = clampf(t[2] * mt.metallic, 0.0f, 1.0f);
             roughness = clampf(t[1] * mt.roughness, 0.05f, 1.0f);
@@ -716,6 +718,7 @@ __global__ void __launch_bounds__(256) k_frag_classify(const DFrame* __restrict_
 #ifndef RDR_SHADE_WAVES
 #define RDR_SHADE_WAVES 4  // waves per SIMD the register allocation is held to (128 VGPRs)
 #endif
+template <bool FLOAT_TEXELS>
 __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_frags(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
                                                                       const DShadeTri* __restrict__ tris, FragLists L) {
     __shared__ float lds_srgb[256];
@@ -777,7 +780,7 @@ __global__ void __launch_bounds__(256, RDR_SHADE_WAVES) k_shade_frags(const DFra
                         todo &= ~__ballot(same);
                     }
                     float c[4];
-                    shade_fragment<false, true>(fr, lights, lds_srgb, tris[rec.x], tris[mat_tri], (int)(rec.y & 0xFFFFu), (int)(rec.y >> 16), c,
+                    shade_fragment<false, true, FLOAT_TEXELS>(fr, lights, lds_srgb, tris[rec.x], tris[mat_tri], (int)(rec.y & 0xFFFFu), (int)(rec.y >> 16), c,
                                                 lds_park + threadIdx.x);
                     colour = pack_half4(c[0], c[1], c[2], c[3]);
                 }
@@ -1030,6 +1033,7 @@ __global__ void __launch_bounds__(256) k_blend_collect(const DView* __restrict__
 }
 
 // One lane per fragment slot; the grid is fixed and strides over the slots in use.
+template <bool FLOAT_TEXELS>
 __global__ void __launch_bounds__(256, 4) k_blend_shade(const DFrame* __restrict__ frp, const DPointLight* __restrict__ lights,
                                                                       const DShadeTri* __restrict__ tris,
                                                                       const uint4* __restrict__ frags, float4* __restrict__ frag_col,
@@ -1044,7 +1048,7 @@ __global__ void __launch_bounds__(256, 4) k_blend_shade(const DFrame* __restrict
         const uint4 m = frags[f];
         if (m.x == BLEND_NONE) continue;
         float c[4];
-        shade_fragment<true, true>(fr, lights, lds_srgb, tris[m.x], tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c, lds_park + threadIdx.x);
+        shade_fragment<true, true, FLOAT_TEXELS>(fr, lights, lds_srgb, tris[m.x], tris[m.x], (int)(m.y & 0xFFFFu), (int)(m.y >> 16), c, lds_park + threadIdx.x);
         frag_col[f] = make_float4(c[0], c[1], c[2], c[3]);
     }
 }
@@ -1117,8 +1121,10 @@ void launch_frag_classify(hipStream_t s, int samples, const DFrame* fr, const ui
     if (samples == 1) hipLaunchKernelGGL(k_frag_classify<1>, dim3(grid), dim3(256), 0, s, fr, vis, L);
     else hipLaunchKernelGGL(k_frag_classify<4>, dim3(grid), dim3(256), 0, s, fr, vis, L);
 }
-void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks) {
-    hipLaunchKernelGGL(k_shade_frags, dim3(blocks), dim3(256), 0, s, fr, lights, tris, L);
+void launch_shade_frags(hipStream_t s, const DFrame* fr, const DPointLight* lights, const DShadeTri* tris, const FragLists& L, uint32_t blocks,
+                        bool float_texels) {
+    if (float_texels) hipLaunchKernelGGL(k_shade_frags<true>, dim3(blocks), dim3(256), 0, s, fr, lights, tris, L);
+    else hipLaunchKernelGGL(k_shade_frags<false>, dim3(blocks), dim3(256), 0, s, fr, lights, tris, L);
 }
 void launch_vis_from_lists(hipStream_t s, int samples, const FragLists& L, uint32_t W, uint32_t H, uint32_t* vis) {
     const uint32_t tiles = ((W + RDR_TILE - 1) / RDR_TILE) * ((H + RDR_TILE - 1) / RDR_TILE);
@@ -1133,7 +1139,7 @@ void launch_frag_resolve(hipStream_t s, int samples, const DFrame* fr, const Fra
 }
 void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPointLight* lights, const DView* view, const DShadeTri* tris, const DTriRec* recs,
                          const uint32_t* sorted_vals, const uint32_t* tile_start, const uint32_t* tile_end, uint32_t tile0, uint32_t n_tiles, void* color,
-                         void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity) {
+                         void* hdr, void* frags, void* frag_col, uint32_t* frag_head, uint32_t* frag_used, uint32_t capacity, bool float_texels) {
     if (!n_tiles) return;
     if (samples == 1)
         hipLaunchKernelGGL((k_blend_collect<1, false>), dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
@@ -1141,7 +1147,10 @@ void launch_raster_blend(hipStream_t s, int samples, const DFrame* fr, const DPo
     else
         hipLaunchKernelGGL((k_blend_collect<4, false>), dim3(n_tiles), dim3(256), 0, s, view, recs, sorted_vals, tile_start, tile_end, (uint4*)frags, frag_head,
                            frag_used, capacity, tile0, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_blend_shade, dim3(RDR_BLEND_SHADE_BLOCKS), dim3(256), 0, s, fr, lights, tris, (const uint4*)frags, (float4*)frag_col, frag_used, capacity);
+    if (float_texels)
+        hipLaunchKernelGGL(k_blend_shade<true>, dim3(RDR_BLEND_SHADE_BLOCKS), dim3(256), 0, s, fr, lights, tris, (const uint4*)frags, (float4*)frag_col, frag_used, capacity);
+    else
+        hipLaunchKernelGGL(k_blend_shade<false>, dim3(RDR_BLEND_SHADE_BLOCKS), dim3(256), 0, s, fr, lights, tris, (const uint4*)frags, (float4*)frag_col, frag_used, capacity);
     if (samples == 1)
         hipLaunchKernelGGL(k_blend_resolve<1>, dim3(n_tiles), dim3(256), 0, s, view, tile_start, tile_end, (const uint4*)frags, (const float4*)frag_col,
                            frag_head, (const uint2*)color, (uint2*)hdr, tile0);

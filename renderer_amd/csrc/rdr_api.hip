@@ -93,6 +93,8 @@ struct HostImage {
     DevBuf pixels;
     uint32_t w = 0, h = 0, levels = 0;
     bool srgb = false;
+    bool is_float = false;   // an SFLOAT format of Image.h: one float4 per texel instead of RGBA8
+    bool half_texels = false;  // ... whose texels are binary16 in the image (every level holds values rounded to it)
     uint32_t level_offset[RDR_MAX_TEX_LEVELS] = {0};
 };
 struct HostTexture { uint32_t image; rdr_sampler sampler; };
@@ -180,6 +182,7 @@ struct rdr_ctx {
     uint32_t lut_w = 0, lut_h = 0;
 
     // frame targets
+    bool float_images = false;  // an image of an SFLOAT format exists: the shading kernels are launched in the build that samples those
     DevBuf d_depth, d_vis, d_samples, d_hdr, d_bloom, d_out, d_loglum, d_lum, d_dir_shadow, d_point_shadow, d_point_static;
     uint32_t bloom_offset[6], bloom_w[6], bloom_h[6], bloom_fin_offset[2];
     bool keep_intermediates = false;  // rdr_keep_intermediates: the tonemap kernel also stores mip 0 and the whole log-luminance image
@@ -577,7 +580,7 @@ int upload_scene(rdr_ctx* c) {
             d.w = img.w; d.h = img.h; d.levels = img.levels;
             const uint32_t nearest = (t.sampler.mag_filter == RDR_FILTER_NEAREST ? 1u : 0u) | (t.sampler.min_filter == RDR_FILTER_NEAREST ? 2u : 0u) |
                                      (t.sampler.mipmap_filter == RDR_FILTER_NEAREST ? 4u : 0u);
-            d.flags = (img.srgb ? 1u : 0u) | (t.sampler.wrap_u << 4) | (t.sampler.wrap_v << 8) | (nearest << 12);
+            d.flags = (img.srgb ? 1u : 0u) | (t.sampler.wrap_u << 4) | (t.sampler.wrap_v << 8) | (nearest << 12) | (img.is_float ? 1u << 16 : 0u);
             memcpy(d.level_offset, img.level_offset, sizeof d.level_offset);
         }
         HIP_TRY(c->d_textures.ensure(dt.size() * sizeof(DTexture)));
@@ -587,9 +590,11 @@ int upload_scene(rdr_ctx* c) {
     return RDR_OK;
 }
 
-int create_image(rdr_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h, bool srgb, uint32_t max_mips, uint32_t* out_id) {
+// `texels`: level 0, RGBA8 (4 bytes per texel) or, with is_float, float4 (16 bytes per texel)
+int create_image(rdr_ctx* c, const void* texels0, uint32_t w, uint32_t h, bool srgb, uint32_t max_mips, uint32_t* out_id, bool is_float = false,
+                 bool half_texels = false) {
     HostImage img;
-    img.w = w; img.h = h; img.srgb = srgb;
+    img.w = w; img.h = h; img.srgb = srgb && !is_float; img.is_float = is_float; img.half_texels = half_texels;
     uint32_t levels = 1;
     const uint32_t m = std::max(w, h);
     if (m > 1) levels = (uint32_t)floor(log2((double)m)) + 1;  // VulkanRenderer.cpp:311-315
@@ -600,13 +605,18 @@ int create_image(rdr_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h, bool s
         img.level_offset[l] = (uint32_t)texels;
         texels += (size_t)std::max(1u, w >> l) * std::max(1u, h >> l);
     }
-    HIP_TRY(img.pixels.ensure(texels * 4 + 16));  // the shading kernels read texel pairs: one texel of slack after the last level
-    HIP_TRY(hipMemcpyAsync(img.pixels.p, rgba, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream));
-    const float* tables = c->d_tables.as<float>();
-    launch_mip_chain(c->stream, img.pixels.as<uint32_t>(), img.level_offset, w, h, levels, srgb ? 1 : 0, tables, tables + 256, tables + 512);
+    const size_t texel_bytes = is_float ? 16u : 4u;
+    HIP_TRY(img.pixels.ensure(texels * texel_bytes + 16));  // the shading kernels read texel pairs: one texel of slack after the last level
+    HIP_TRY(hipMemcpyAsync(img.pixels.p, texels0, (size_t)w * h * texel_bytes, hipMemcpyHostToDevice, c->stream));
+    if (is_float) launch_mip_chain_f32(c->stream, img.pixels.as<float>(), img.level_offset, w, h, levels, half_texels);
+    else {
+        const float* tables = c->d_tables.as<float>();
+        launch_mip_chain(c->stream, img.pixels.as<uint32_t>(), img.level_offset, w, h, levels, srgb ? 1 : 0, tables, tables + 256, tables + 512);
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     c->images.push_back(img);
+    if (is_float) c->float_images = true;
     *out_id = (uint32_t)c->images.size() - 1;
     return RDR_OK;
 }
@@ -1343,17 +1353,37 @@ int rdr_load_buffer(rdr_ctx* c, const void* ptr, size_t size, uint32_t* out_id) 
 
 int rdr_load_image(rdr_ctx* c, const void* ptr, size_t size, uint32_t w, uint32_t h, int format, uint32_t max_mips, uint32_t* out_id) {
     if (!c || !ptr || !out_id || w == 0 || h == 0) return fail(c, RDR_ERR_INVALID, "load_image: bad argument");
-    int ch; bool srgb;
+    int ch; bool srgb = false; int float_bytes = 0;  // bytes per component of an SFLOAT format, 0 for the 8-bit ones
     switch (format) {
-        case RDR_FORMAT_R8G8B8_UNORM: ch = 3; srgb = false; break;
+        case RDR_FORMAT_R8G8B8_UNORM: ch = 3; break;
         case RDR_FORMAT_R8G8B8_SRGB: ch = 3; srgb = true; break;
-        case RDR_FORMAT_R8G8B8A8_UNORM: ch = 4; srgb = false; break;
+        case RDR_FORMAT_R8G8B8A8_UNORM: ch = 4; break;
         case RDR_FORMAT_R8G8B8A8_SRGB: ch = 4; srgb = true; break;
-        default: return fail(c, RDR_ERR_UNSUPPORTED, "load_image: only 8-bit formats are supported");
+        case RDR_FORMAT_R16G16B16_SFLOAT: ch = 3; float_bytes = 2; break;
+        case RDR_FORMAT_R16G16B16A16_SFLOAT: ch = 4; float_bytes = 2; break;
+        case RDR_FORMAT_R32G32B32_SFLOAT: ch = 3; float_bytes = 4; break;
+        case RDR_FORMAT_R32G32B32A32_SFLOAT: ch = 4; float_bytes = 4; break;
+        default: return fail(c, RDR_ERR_INVALID, "load_image: unknown format");
     }
-    if (size < (size_t)w * h * ch) return fail(c, RDR_ERR_INVALID, "load_image: size too small");
+    if (size < (size_t)w * h * ch * (float_bytes ? float_bytes : 1)) return fail(c, RDR_ERR_INVALID, "load_image: size too small");
     if (w > 32768u || h > 32768u) return fail(c, RDR_ERR_UNSUPPORTED, "load_image: images larger than 32768 texels on a side are not supported");
     HIP_TRY(hipSetDevice(c->device));
+    if (float_bytes) {
+        // the SFLOAT formats (Image.h:9-12) are held as one float4 per texel; a missing alpha reads as 1 (the Vulkan rule
+        // for a format without that component)
+        std::vector<float> f4((size_t)w * h * 4);
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            for (int k = 0; k < 4; k++) {
+                float v = 1.0f;
+                if (k < ch) {
+                    if (float_bytes == 2) { _Float16 hv; memcpy(&hv, (const uint8_t*)ptr + (i * ch + k) * 2, 2); v = (float)hv; }
+                    else memcpy(&v, (const uint8_t*)ptr + (i * ch + k) * 4, 4);
+                }
+                f4[i * 4 + k] = v;
+            }
+        }
+        return create_image(c, f4.data(), w, h, false, max_mips, out_id, true, float_bytes == 2);
+    }
     const uint8_t* s = (const uint8_t*)ptr;
     std::vector<uint8_t> rgba;
     if (ch == 3) {
@@ -2032,7 +2062,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         if (!fused_classify) launch_frag_classify(c->stream2, (int)S, c->d_frame.as<DFrame>(), c->d_vis.as<uint32_t>(), L);
         if (ts != c->stream2 && c->pending[prev_slot(c)].on) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_sets[prev_slot(c)][9], 0));
         HIP_TRY(hipEventRecord(c->ev[6], c->stream2));
-        launch_shade_frags(c->stream2, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, L, c->shade_blocks);
+        launch_shade_frags(c->stream2, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), tris_main, L, c->shade_blocks, c->float_images);
         HIP_TRY(hipEventRecord(c->ev[7], c->stream2));
         if (ts != c->stream2) HIP_TRY(hipStreamWaitEvent(ts, c->ev[7], 0));
         launch_frag_resolve(ts, (int)S, c->d_frame.as<DFrame>(), L, c->d_hdr.p, (S == 4 && have_blend) ? c->d_samples.p : nullptr,
@@ -2054,7 +2084,7 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
             launch_raster_blend(ts, (int)S, c->d_frame.as<DFrame>(), c->d_lights.as<DPointLight>(), c->d_views.as<DView>() + (main_view + 1),
                                 tris_blend, c->d_recs.as<DTriRec>(), c->d_vals[cur].as<uint32_t>(), c->d_tile_start.as<uint32_t>(),
                                 c->d_tile_end.as<uint32_t>(), tile0, count, S == 4 ? c->d_samples.p : c->d_hdr.p, c->d_hdr.p, c->d_frags.p,
-                                c->d_frag_col.p, c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, capacity);
+                                c->d_frag_col.p, c->d_frag_head.as<uint32_t>(), frame_counters(c) + RDR_COUNTER_FRAGS, capacity, c->float_images);
         };
         if (bound <= c->blend_budget_slots) {
             HIP_TRY(c->d_frags.ensure(bound * 16));
@@ -2321,7 +2351,8 @@ int rdr_read_image_level(rdr_ctx* c, uint32_t image, uint32_t level, uint8_t* ou
     const uint32_t w = std::max(1u, img.w >> level), h = std::max(1u, img.h >> level);
     if (ow) *ow = w;
     if (oh) *oh = h;
-    if (out) return read_back(c, out, img.pixels.as<uint32_t>() + img.level_offset[level], (size_t)w * h * 4);
+    const size_t texel_bytes = img.is_float ? 16u : 4u;
+    if (out) return read_back(c, out, img.pixels.as<uint8_t>() + (size_t)img.level_offset[level] * texel_bytes, (size_t)w * h * texel_bytes);
     return RDR_OK;
 }
 

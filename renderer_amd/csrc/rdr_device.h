@@ -42,11 +42,11 @@ struct DVertexAttr {
     float _pad;
 };  // 48 bytes
 
-// One texture = image (all mip levels, RGBA8, level-major) + sampler state.
+// One texture = image (all mip levels, level-major; RGBA8, or for the float formats of Image.h one float4 per texel) + sampler state.
 struct DTexture {
     const uint8_t* base;
     uint32_t w, h, levels;
-    uint32_t flags;  // bit0 sRGB, bits 4..5 wrap_u, bits 8..9 wrap_v, bits 12..14 NEAREST for mag / min / mipmap mode
+    uint32_t flags;  // bit0 sRGB, bits 4..5 wrap_u, bits 8..9 wrap_v, bits 12..14 NEAREST for mag / min / mipmap mode, bit 16 float texels
     uint32_t level_offset[RDR_MAX_TEX_LEVELS];  // in texels
 };
 
@@ -120,10 +120,11 @@ struct DTriRec {
 #define RDR_TEXD_SRGB 1u        // flags bit 0
 #define RDR_TEXD_POW2_SQUARE 2u  // flags bit 1: w == h == 2^n with a complete chain, level offsets are arithmetic
 #define RDR_TEXD_NEAREST_SHIFT 6u  // flags bits 6..8: the Sampler's magFilter / minFilter / mipmapFilter is NEAREST
+#define RDR_TEXD_FLOAT 512u       // flags bit 9: texels are float4 (the SFLOAT formats of Image.h), not RGBA8
 struct DTexDesc {
-    const uint8_t* base;  // RGBA8 texels, all levels
+    const uint8_t* base;  // texels, all levels: RGBA8, or float4 with RDR_TEXD_FLOAT
     uint32_t wh;          // w | h << 16
-    uint32_t info;        // levels (5 bits) | flags << 5 (srgb, pow2-square, wrap_u << 2, wrap_v << 4, nearest filters << 6) | texture index << 16
+    uint32_t info;        // levels (5 bits) | flags << 5 (srgb, pow2-square, wrap_u << 2, wrap_v << 4, nearest filters << 6, float << 9) | texture index << 16
 };  // 16 bytes
 
 // Everything the fragments of one triangle share: the vertex-stage outputs

@@ -263,6 +263,8 @@ def bilinear_repeat(level, u, v, modes=(REPEAT, REPEAT)):
 def decode_texels(u8, srgb):
     """RGBA8 bytes -> float texels as the sampler sees them: sRGB images decode R, G, B before filtering (alpha is
     always linear), UNORM images are byte / 255."""
+    if np.asarray(u8).dtype != np.uint8:
+        return np.asarray(u8, np.float64)  # a level of an SFLOAT image: the sampler sees the stored values
     t = np.asarray(u8, np.float64) / 255.0
     if srgb:
         t = t.copy()
@@ -357,6 +359,19 @@ def blit_linear(src_u8, dw, dh, srgb):
         rgb = np.clip(val[..., :3], 0.0, 1.0)
         out[..., :3] = np.where(rgb <= 0.0031308, rgb * 12.92, 1.055 * rgb ** (1 / 2.4) - 0.055) * 255.0
     return out
+
+
+def blit_linear_float(src, dw, dh):
+    """blit_linear for a level of float texels [sh, sw, C] (float64 in, float64 out, no encoding)."""
+    sh, sw = src.shape[:2]
+    i, j = np.meshgrid(np.arange(dw), np.arange(dh), indexing="xy")
+    x, y = (i + 0.5) * (sw / dw) - 0.5, (j + 0.5) * (sh / dh) - 0.5
+    i0, j0 = np.floor(x), np.floor(y)
+    a, b = (x - i0)[..., None], (y - j0)[..., None]
+    i0, j0 = i0.astype(np.int64), j0.astype(np.int64)
+    ci = lambda k: np.clip(k, 0, sw - 1)  # noqa: E731
+    cj = lambda k: np.clip(k, 0, sh - 1)  # noqa: E731
+    return (1 - b) * ((1 - a) * src[cj(j0), ci(i0)] + a * src[cj(j0), ci(i0 + 1)]) + b * ((1 - a) * src[cj(j0 + 1), ci(i0)] + a * src[cj(j0 + 1), ci(i0 + 1)])
 
 
 def cube_shadow_compare(depth_cube, d, ref, eps=2e-6):

@@ -103,7 +103,21 @@ FILTERS = dict(ground=(LIN, LIN, NEAR),    # minified over many levels: one leve
                card=(NEAR, NEAR, NEAR))    # the textured alpha of the MASK card, unfiltered
 
 
-def detail_prims(filters=None):
+# the "float" variant: the five images of each primitive in one of the SFLOAT formats of Image.h:9-12, holding the values
+# the 8-bit images decode to (sRGB decoded for the base colour), so that the scene looks the same and only the path differs
+FLOAT_FORMATS = dict(ground=B.FORMAT_R32G32B32A32_SFLOAT, box=B.FORMAT_R16G16B16A16_SFLOAT, wall=B.FORMAT_R32G32B32_SFLOAT,
+                     mover=B.FORMAT_R16G16B16_SFLOAT, card=B.FORMAT_R16G16B16A16_SFLOAT)
+
+
+def float_image(u8, srgb, fmt):
+    """An 8-bit image as the float image of format `fmt` that holds its decoded values."""
+    t = G.decode_texels(u8, srgb)
+    half = fmt in (B.FORMAT_R16G16B16_SFLOAT, B.FORMAT_R16G16B16A16_SFLOAT)
+    ch = 3 if fmt in (B.FORMAT_R16G16B16_SFLOAT, B.FORMAT_R32G32B32_SFLOAT) else 4
+    return np.ascontiguousarray(t[..., :ch].astype(np.float16 if half else np.float32))
+
+
+def detail_prims(filters=None, float_formats=None):
     """Opaque primitives, then MASK / BLEND ones, of the "detail" variant. `images` holds level 0 of the five textures;
     the chains are read back from the renderer (build() stores the image ids). `filters`: None for LINEAR samplers,
     or a dict primitive -> (magFilter, minFilter, mipmapFilter)."""
@@ -133,6 +147,11 @@ def detail_prims(filters=None):
     if filters is not None:
         for name, p in (("ground", ground), ("box", box), ("wall", wall), ("mover", mover), ("card", card)):
             p.mat["filters"] = filters[name]
+    if float_formats is not None:
+        for name, p in (("ground", ground), ("box", box), ("wall", wall), ("mover", mover), ("card", card)):
+            fmt = float_formats[name]
+            p.mat["float_format"] = fmt
+            p.mat["images"] = {k: float_image(v, k == "albedo", fmt) for k, v in p.mat["images"].items()}
     return [ground, box, wall, mover], [card]
 
 
@@ -142,6 +161,8 @@ def prims(variant="base"):
         return detail_prims()
     if variant == "filters":
         return detail_prims(FILTERS)
+    if variant == "float":
+        return detail_prims(float_formats=FLOAT_FORMATS)
     ground = KatPrim(scenes.plane(30, 30, 1, 1), scenes.translation(0, 0, -12) @ G.rotate(0.1, 2) @ SCALE,
                      _mat((200, 150, 100, 255), (150, 110, 240, 255), (0, 180, 60, 255), (210, 0, 0, 255), (30, 60, 90, 255),
                           base_color=(0.9, 0.8, 0.7, 1.0), emissive=(0.5, 0.25, 0.125), metallic=0.9, roughness=0.8, ao=0.9))
@@ -175,7 +196,7 @@ def build(r, env_faces, lut=None, with_meshes=True, variant="base"):
         for p in opaque + blended:
             m = p.mat
             if "images" in m:
-                m["image_ids"] = [r.load_image(m["images"][name], f) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
+                m["image_ids"] = [r.load_image(m["images"][name], m.get("float_format", f)) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
                 tex = [r.make_texture(i, *m["wrap"], *m.get("filters", (LIN, LIN, LIN))) for i in m["image_ids"]]
             else:
                 tex = [r.make_texture(r.load_image(np.asarray(m[name], np.uint8).reshape(1, 1, 4), f)) for name, f in zip(TEXTURE_NAMES, TEXTURE_FORMATS)]
@@ -204,6 +225,23 @@ def read_chains(r, opaque, blended):
             h, w = m["images"][name].shape[:2]
             count = int(np.floor(np.log2(max(w, h)))) + 1   # VulkanRenderer.cpp:311-315
             levels = [r.read_image_level(image, l) for l in range(count)]
+            if "float_format" in m:
+                # float4 texels as stored: the given components, 1 for a missing alpha; each level the float64 blit of the
+                # one above it, computed in float32 and, for the 16-bit formats, rounded to binary16
+                given = m["images"][name]
+                assert levels[0].dtype == np.float32 and np.array_equal(levels[0][..., :given.shape[-1]], given.astype(np.float32))
+                assert given.shape[-1] == 4 or np.all(levels[0][..., 3] == 1.0)
+                half = given.dtype == np.float16
+                for l in range(1, count):
+                    assert levels[l].shape[:2] == (max(1, h >> l), max(1, w >> l))
+                    exact = G.blit_linear_float(levels[l - 1].astype(np.float64), levels[l].shape[1], levels[l].shape[0])
+                    tol = 2.0 ** -11 * 1.01 if half else 4e-7
+                    assert np.all(np.abs(levels[l] - exact) <= tol * np.maximum(np.abs(exact), 2.0 ** -14) + 1e-12), (name, l)
+                    if half:
+                        assert np.array_equal(levels[l], levels[l].astype(np.float16).astype(np.float32))
+                    n_levels += 1
+                m["chains"][name] = levels
+                continue
             assert np.array_equal(levels[0], m["images"][name])
             for l in range(1, count):
                 assert levels[l].shape[:2] == (max(1, h >> l), max(1, w >> l))
@@ -305,7 +343,7 @@ def expected_hdr(r, W, H, margin, variant="base", built=None, details=None):
             for i, sh in enumerate(info["point_shadow"]):
                 details["point_shadow"][i][ys, xs] = sh
             if p.mat.get("chains"):
-                levels = [G.decode_texels(lv, True) for lv in p.mat["chains"]["albedo"]]
+                levels = [G.decode_texels(lv, True) for lv in p.mat["chains"]["albedo"]]  # only the sizes matter here
                 details["lod"][ys, xs] = G.texture_lod(levels, frag["duvdx"][:, 0], frag["duvdx"][:, 1], frag["duvdy"][:, 0], frag["duvdy"][:, 1])
         return ys, xs, rgba, robust
 

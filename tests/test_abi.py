@@ -128,9 +128,8 @@ def test_settings_the_checker_refuses(orc_capi):
 
 
 def test_resources_the_checker_refuses(orc_capi):
-    """Image formats other than 8-bit RGB(A) (Image.h:5-14) are refused with RDR_ERR_UNSUPPORTED; the 8-bit formats and
-    every combination of the Sampler's filters (VulkanRenderer.cpp:363-385) are accepted, values outside the enums are
-    invalid."""
+    """Every ImageFormat of Image.h:5-14 and every combination of the Sampler's filters (VulkanRenderer.cpp:363-385) is
+    accepted; values outside the enums and buffers too small for the format are invalid."""
     _check_resource_refusals(orc_capi)
 
 
@@ -144,11 +143,14 @@ def _check_resource_refusals(api):
         r.load_image(px, fmt)
     for fmt in (B.FORMAT_R8G8B8_UNORM, B.FORMAT_R8G8B8_SRGB):
         r.load_image(px[..., :3], fmt)
-    for fmt in (4, 5, 6, 7):  # the 16- and 32-bit float formats of Image.h
+    for fmt, texel_bytes in ((4, 6), (5, 8), (6, 12), (7, 16)):  # the 16- and 32-bit float formats of Image.h
         out = C.c_uint32()
-        buf = np.zeros(4 * 4 * 16, np.uint8)
-        rc = api.load_image(r._ctx, buf.ctypes.data_as(C.c_void_p), buf.size, 4, 4, fmt, 1, C.byref(out))
-        assert rc == B.RDR_ERR_UNSUPPORTED, fmt
+        buf = np.zeros(4 * 4 * texel_bytes, np.uint8)
+        assert api.load_image(r._ctx, buf.ctypes.data_as(C.c_void_p), buf.size, 4, 4, fmt, 1, C.byref(out)) == B.RDR_OK, fmt
+        assert api.load_image(r._ctx, buf.ctypes.data_as(C.c_void_p), buf.size - 1, 4, 4, fmt, 1, C.byref(out)) == B.RDR_ERR_INVALID, fmt
+    out = C.c_uint32()
+    buf = np.zeros(4 * 4 * 16, np.uint8)
+    assert api.load_image(r._ctx, buf.ctypes.data_as(C.c_void_p), buf.size, 4, 4, 8, 1, C.byref(out)) == B.RDR_ERR_INVALID
     img = r.load_image(px, B.FORMAT_R8G8B8A8_UNORM)
     for bits in range(8):
         filt = [B.FILTER_NEAREST if bits >> k & 1 else B.FILTER_LINEAR for k in range(3)]

@@ -196,6 +196,15 @@ def test_mip_chain_parity(orc_capi, hip_capi, size):
             assert np.array_equal(lo, lh), f"format {fmt} level {level} of {w}x{h}"
         with pytest.raises(Exception):
             rh.read_image_level(ih, n_levels)
+    # the SFLOAT formats (Image.h:9-12): float texels, the 16-bit ones rounded to binary16 level by level
+    for fmt, ch, dt in ((scenes.B.FORMAT_R32G32B32A32_SFLOAT, 4, np.float32), (scenes.B.FORMAT_R32G32B32_SFLOAT, 3, np.float32),
+                        (scenes.B.FORMAT_R16G16B16A16_SFLOAT, 4, np.float16), (scenes.B.FORMAT_R16G16B16_SFLOAT, 3, np.float16)):
+        img = (rng.random((h, w, ch), dtype=np.float32) ** 3 * 8.0).astype(dt)
+        io, ih = ro.load_image(img, fmt), rh.load_image(img, fmt)
+        for level in range(n_levels):
+            lo, lh = ro.read_image_level(io, level), rh.read_image_level(ih, level)
+            assert lo.dtype == np.float32 and lo.shape == (max(1, h >> level), max(1, w >> level), 4)
+            assert np.array_equal(lo.view(np.uint32), lh.view(np.uint32)), f"format {fmt} level {level} of {w}x{h}"
     # max_mip_levels cuts the chain short
     img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
     io, ih = ro.load_image(img, scenes.B.FORMAT_R8G8B8A8_UNORM, max_mip_levels=2), rh.load_image(img, scenes.B.FORMAT_R8G8B8A8_UNORM, max_mip_levels=2)

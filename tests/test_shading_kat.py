@@ -217,6 +217,18 @@ def test_nearest_sampler_filters(orc_capi, msaa):
     print(check_detail(orc_capi, msaa, variant="filters"))
 
 
+def test_float_image_formats(orc_capi):
+    """The SFLOAT formats of Image.h:9-12 as material textures: float texels filtered as they are, 16-bit ones rounded
+    level by level, a missing alpha read as 1; the same scene, the same float64 expectations."""
+    print(check_detail(orc_capi, 1, variant="float"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_float_image_formats_hip(hip_capi, msaa):
+    print(check_detail(hip_capi, msaa, variant="float"))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("msaa", [1, 4])
 def test_nearest_sampler_filters_hip(hip_capi, msaa):
