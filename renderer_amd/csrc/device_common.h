@@ -286,18 +286,6 @@ RDR_DEV void cube_sample_quad(const DCube& cube, uint32_t level, float dx, float
 // ---- 2D material textures: trilinear, isotropic LOD
 #define RDR_INV255 (1.0f / 255.0f)
 
-RDR_DEV int wrap_index(int i, int n, uint32_t mode) {
-    if (mode == 0u) {
-        if ((n & (n - 1)) == 0) return i & (n - 1);  // power-of-two size: two's complement AND is the floor modulo
-        int r = i % n; return r < 0 ? r + n : r;
-    }
-    if (mode == 1u) {
-        const int period = 2 * n;
-        int r = i % period; if (r < 0) r += period;
-        return r < n ? r : period - 1 - r;
-    }
-    return min(max(i, 0), n - 1);
-}
 // `srgb` points at the 256-entry sRGB decode table (LDS copy in the hot kernels).
 // UNORM channels decode as byte * (1/255). MASK selects the channels the caller
 // reads (bit k = channel k); the others are left untouched. `table` is the
@@ -313,12 +301,20 @@ RDR_DEV uint32_t tex_level_offset(const DTexDesc& t, const DTexture* __restrict_
     }
     return as_global(table)[t.info >> 16].level_offset[level];
 }
-// Texel pair (i0, i0 + 1) and weight along one axis. REPEAT works on the fractional part of the coordinate, which
-// needs no integer modulo; the weight differs from the unwrapped formula only by rounding, and bilinear filtering
-// is continuous across texel boundaries.
+// Texel pair (i0, i0 + 1) and weight along one axis, without an integer modulo. REPEAT works on the fractional part of
+// the coordinate. MIRRORED_REPEAT reflects the coordinate into [0, 1] (period 2) and then clamps the pair to the edge:
+// the wrapping operation maps texel -1 to 0 and texel n to n - 1, which is what a clamped footprint of the reflected
+// coordinate reads, with the two taps and their weights exchanged on the reflected half. The weights differ from the
+// unwrapped formula only by rounding, and bilinear filtering is continuous across texel boundaries.
+RDR_DEV float tex_reflect(float coord) {
+    const float h = coord * 0.5f;
+    const float m = (h - floorf(h)) * 2.0f;  // coord modulo 2, in [0, 2]
+    return m > 1.0f ? 2.0f - m : m;
+}
 RDR_DEV void tex_axis(float coord, int n, uint32_t mode, int& i0, int& i1, float& a) {
 #pragma clang fp contract(fast)
     if (mode == 0u) coord -= floorf(coord);
+    else if (mode == 1u) coord = tex_reflect(coord);
     const float tc = coord * (float)n - 0.5f;
     const float fc = floorf(tc);
     a = tc - fc;
@@ -327,8 +323,10 @@ RDR_DEV void tex_axis(float coord, int n, uint32_t mode, int& i0, int& i1, float
         i0 = i < 0 ? n - 1 : i;
         i1 = i + 1 >= n ? 0 : i + 1;
     } else {
-        i0 = wrap_index((int)fc, n, mode);
-        i1 = wrap_index((int)fc + 1, n, mode);
+        const int i = (int)fmaxf(fminf(fc, (float)n), -1.0f);
+        i0 = max(i, 0);
+        i1 = min(i + 1, n - 1);
+        i0 = min(i0, n - 1);
     }
 }
 // Where a sample lands in an image of given size, levels and wrap modes: the level pair, and per level the four
@@ -348,7 +346,8 @@ RDR_DEV int tex_axis_nearest(float coord, int n, uint32_t mode) {
         const int i = (int)floorf(coord * (float)n);  // in [0, n]: n when the product rounds up
         return i >= n ? 0 : i;
     }
-    return wrap_index((int)floorf(coord * (float)n), n, mode);
+    if (mode == 1u) coord = tex_reflect(coord);
+    return (int)fminf(fmaxf(floorf(coord * (float)n), 0.0f), (float)(n - 1));
 }
 RDR_DEV void tex_level_taps(const DTexDesc& t, const DTexture* __restrict__ table, uint32_t level, float u, float v, bool nearest, TexLevelTaps& o) {
     const uint32_t ww = (t.wh & 0xFFFFu) >> level, hh = (t.wh >> 16) >> level;
