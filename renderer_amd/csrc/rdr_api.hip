@@ -1188,7 +1188,14 @@ int ensure_post_targets(rdr_ctx* c) {
     // the accumulated mips 3 and 4 of the fused up-sample kernel (launch_bloom_chain)
     c->bloom_fin_offset[0] = (uint32_t)off; off += ((size_t)c->bloom_w[3] * c->bloom_h[3] + 3u) & ~(size_t)3u;
     c->bloom_fin_offset[1] = (uint32_t)off; off += (size_t)c->bloom_w[4] * c->bloom_h[4];
-    HIP_TRY(c->d_bloom.ensure(off * 4));
+    // A bloom level whose dispatch has no groups (the reference's extent is W >> l x H >> l, VulkanRendererBloom.cpp:82,
+    // while the level itself is never smaller than 1 x 1) is never written and is read by the up-sample above it. The
+    // reference leaves its contents undefined; here it reads as zero: the buffer is cleared when it is created, and
+    // nothing ever writes such a level.
+    if (c->d_bloom.cap < off * 4) {
+        HIP_TRY(c->d_bloom.ensure(off * 4));
+        HIP_TRY(hipMemset(c->d_bloom.p, 0, c->d_bloom.cap));
+    }
     HIP_TRY(c->d_out.ensure(n * out_pixel_bytes(c)));
     HIP_TRY(c->d_loglum.ensure(n * 4));
     HIP_TRY(c->d_lum.ensure((256 + 16) * 4));
@@ -2402,6 +2409,9 @@ int rdr_post_process_noalloc(rdr_ctx* c, const void* hdr_rgba16f, uint32_t width
     if (fin4_at + (size_t)bw[4] * bh[4] > NOALLOC_BLOOM_WORDS)
         return fail(c, RDR_ERR_CAPACITY, "post_process_noalloc: the six bloom mips of this image (every level at least one texel wide and high) need "
                                          "more than 1.5 x RDR_NOALLOC_MAX_PIXELS texels; use rdr_post_process");
+    // the array keeps the last call's contents: a level no down-sample writes (a side shorter than 2^l) must read as zero
+    for (uint32_t l = 1; l < 6; l++)
+        if ((width >> l) == 0u || (height >> l) == 0u) HIP_TRY(hipMemsetAsync(bloom + off[l], 0, (size_t)bw[l] * bh[l] * 4u, st));
     // the same launches, in the same order, as enqueue_post
     uint32_t* mip[6];
     int mw[6], mh[6];

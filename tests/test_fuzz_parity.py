@@ -1,0 +1,20 @@
+"""Random scenes (tools/fuzz_parity.py): the HIP library against the CPU checker, one context after the other in one
+process. Depth, visibility and every shadow map bit for bit; the 8-bit frame within one step but for single pixels on
+a discontinuity. A frame shorter than 32 pixels has a bloom level no down-sample writes (the reference's dispatch
+extent is W >> l x H >> l, VulkanRendererBloom.cpp:82): it must read as zero whatever memory the context was given,
+which a run of contexts in one process is what exposes."""
+import pytest
+
+from tools import fuzz_parity as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_scenes(orc_capi, hip_capi):
+    worst = 0.0
+    for seed in range(0, 16):
+        ok, share = F.one(seed, orc_capi, hip_capi)
+        assert ok, seed
+        assert share <= 0.002, (seed, share)
+        worst = max(worst, share)
+    print("largest share of pixels further apart than one step:", worst)

@@ -12,7 +12,7 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("size", [(64, 48), (250, 141), (640, 360), (391, 287), (128, 135)])
+@pytest.mark.parametrize("size", [(64, 48), (250, 141), (640, 360), (391, 287), (128, 135), (138, 26), (20, 300)])
 def test_post_process_parity(orc_capi, hip_capi, size):
     W, H = size
     ro, rh = hp.make_pair(orc_capi, hip_capi, W, H)

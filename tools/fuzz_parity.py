@@ -1,0 +1,170 @@
+"""Randomised parity runs: the HIP library against the CPU checker on scenes nobody designed.
+
+  python tools/fuzz_parity.py [first_seed] [count]
+
+Every seed makes one scene: a few triangle soups (small, huge, crossing the near plane, slivers, repeated vertices),
+materials with random alpha modes, wrap modes, filters, image sizes and formats, up to six point lights of which some
+cast shadows, a random camera, frame size and sample count. Depth, visibility, cascades and point-light faces must be
+equal bit for bit; the 8-bit frame is compared pixel by pixel and the share of pixels further apart than one step is
+reported (a discontinuous choice - alpha cut-off, NEAREST texel, mipmap rounding, cascade selection - can fall on
+either side in two float32 implementations, so single pixels may differ; more than a few per thousand is a finding).
+Prints one line per seed and exits non-zero at the first exact mismatch."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from oracle import orc  # noqa: E402
+from renderer_amd import _binding as B  # noqa: E402
+from renderer_amd import scenes  # noqa: E402
+from renderer_amd.api import Renderer, default_settings, load_hip_capi  # noqa: E402
+
+
+def soup(rng, kind, n):
+    """n random triangles as a Geo with per-vertex frames."""
+    if kind == 0:      # pebbles around the origin
+        centre = rng.normal(0, 2.0, (n, 1, 3)); size = rng.uniform(0.02, 0.8, (n, 1, 1))
+    elif kind == 1:    # large sheets, some through the camera
+        centre = rng.normal(0, 4.0, (n, 1, 3)); size = rng.uniform(2.0, 30.0, (n, 1, 1))
+    elif kind == 2:    # slivers
+        centre = rng.normal(0, 3.0, (n, 1, 3)); size = rng.uniform(0.5, 5.0, (n, 1, 1))
+    else:              # dust: sub-pixel triangles far away
+        centre = rng.normal(0, 1.0, (n, 1, 3)) + np.array([0, 0, -25.0]); size = rng.uniform(0.001, 0.05, (n, 1, 1))
+    tri = centre + rng.normal(0, 1.0, (n, 3, 3)) * size
+    if kind == 2:
+        tri[:, 2] = tri[:, 0] + (tri[:, 1] - tri[:, 0]) * rng.uniform(0.2, 0.8, (n, 1)) + rng.normal(0, 1e-3, (n, 3))
+    if n > 4:
+        tri[1] = tri[0]            # the same triangle twice: a depth tie over a whole triangle
+        tri[2, 2] = tri[2, 1]      # two equal vertices: no area
+    pos = tri.reshape(-1, 3).astype(np.float32)
+    e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    nrm = np.cross(e1, e2)
+    ln = np.linalg.norm(nrm, axis=-1, keepdims=True)
+    nrm = np.where(ln > 1e-12, nrm / np.maximum(ln, 1e-12), np.array([0.0, 1.0, 0.0]))
+    le = np.linalg.norm(e1, axis=-1, keepdims=True)
+    tan = np.where(le > 1e-12, e1 / np.maximum(le, 1e-12), np.array([1.0, 0.0, 0.0]))
+    nrm = np.repeat(nrm, 3, 0).astype(np.float32)
+    tan4 = np.concatenate([np.repeat(tan, 3, 0), np.where(rng.random((3 * n, 1)) < 0.5, -1.0, 1.0)], -1).astype(np.float32)
+    uv = (rng.uniform(-3.0, 4.0, (3 * n, 2)) * rng.choice([0.05, 1.0, 8.0])).astype(np.float32)
+    return scenes.Geo(pos, nrm, tan4, uv, np.arange(3 * n, dtype=np.uint32))
+
+
+def random_images(rng):
+    """Five images of one random size and a random format family."""
+    w, h = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    if rng.random() < 0.5:
+        w = h = int(2 ** rng.integers(0, 7))
+    family = rng.choice(["u8", "u8", "u8", "rgb8", "f16", "f32", "rgb32f"])
+    imgs = []
+    for k in range(5):
+        a = rng.random((h, w, 4))
+        if k == 1:
+            a[..., :3] = a[..., :3] * 0.3 + np.array([0.35, 0.35, 0.7])   # normals that point outwards
+        if family == "u8":
+            imgs.append((scenes.to_u8(a), B.FORMAT_R8G8B8A8_SRGB if k == 0 else B.FORMAT_R8G8B8A8_UNORM))
+        elif family == "rgb8":
+            imgs.append((scenes.to_u8(a)[..., :3], B.FORMAT_R8G8B8_SRGB if k == 0 else B.FORMAT_R8G8B8_UNORM))
+        elif family == "f16":
+            imgs.append((a.astype(np.float16), B.FORMAT_R16G16B16A16_SFLOAT))
+        elif family == "f32":
+            imgs.append((a.astype(np.float32), B.FORMAT_R32G32B32A32_SFLOAT))
+        else:
+            imgs.append((a[..., :3].astype(np.float32), B.FORMAT_R32G32B32_SFLOAT))
+    return imgs
+
+
+def build(r, seed):
+    rng = np.random.default_rng(seed)
+    n_prims = int(rng.integers(1, 6))
+    for p in range(n_prims):
+        geo = soup(rng, int(rng.integers(0, 4)), int(rng.integers(5, 300)))
+        imgs = random_images(rng)
+        wrap = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+        filt = [int(rng.integers(0, 2)) if rng.random() < 0.3 else B.FILTER_LINEAR for _ in range(3)]
+        mips = 1 if rng.random() < 0.2 else 0xFFFFFFFF
+        tex = [r.make_texture(r.load_image(a, f, mips), wrap[0], wrap[1], *filt) for a, f in imgs]
+        if rng.random() < 0.2:
+            tex[3] = tex[2]    # occlusion and metal-roughness in one image
+        if rng.random() < 0.2:
+            tex[int(rng.integers(0, 5))] = B.INVALID_ID   # a slot left to the renderer's default
+        mode = int(rng.choice([B.ALPHA_OPAQUE, B.ALPHA_OPAQUE, B.ALPHA_MASK, B.ALPHA_BLEND]))
+        mat = scenes.make_material(tex, base_color=tuple(rng.uniform(0.2, 1.0, 4)), emissive=tuple(rng.uniform(0, 0.5, 3) * (rng.random() < 0.5)),
+                                   metallic=float(rng.random()), roughness=float(rng.random()), ao=float(rng.uniform(0.5, 1.0)),
+                                   alpha_mode=mode, alpha_cutoff=float(rng.uniform(0.2, 0.8)))
+        model = scenes.translation(*rng.normal(0, 1.0, 3)) @ scenes.rotation_y(float(rng.uniform(0, 6.28))) @ scenes.rotation_x(float(rng.uniform(0, 6.28)))
+        r.add_mesh([scenes.upload_primitive(r, geo, mat, B.UINT32)], model=np.ascontiguousarray(model.T, np.float32), is_static=bool(rng.random() < 0.6))
+    if rng.random() < 0.9:
+        r.set_brdf_lut(scenes.brdf_lut(16, 16))
+        r.set_environment_map(scenes.sky_faces(int(rng.choice([4, 16])), seed=seed))
+    lights = [(tuple(rng.normal(0, 3.0, 3)), tuple(rng.uniform(0, 60.0, 3)), bool(rng.random() < 0.6)) for _ in range(int(rng.integers(0, 7)))]
+    if rng.random() < 0.9:
+        r.set_lights(lights, scenes.default_directional_light())
+    r.set_camera(position=tuple(rng.normal(0, 3.0, 3) + np.array([0, 0, 4.0])), euler=(float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.2, 0.2))),
+                 near=float(rng.choice([0.05, 0.1, 0.5])), far=float(rng.choice([20.0, 60.0, 200.0])))
+
+
+def one(seed, orc_capi, hip_capi):
+    rng = np.random.default_rng(seed + 10 ** 6)
+    W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
+    msaa = int(rng.choice([1, 4]))
+    st = dict(msaa=msaa, directional_shadow_map_resolution=int(rng.choice([64, 200, 512])), point_shadow_map_resolution=int(rng.choice([16, 50, 128])),
+              point_shadow_map_count=int(rng.integers(0, 4)), dynamic_shadows_enabled=int(rng.random() < 0.8))
+    ro = Renderer(orc_capi, W, H, default_settings(**st), keep_intermediates=True)
+    rh = Renderer(hip_capi, W, H, default_settings(**st), keep_intermediates=True)
+    build(ro, seed); build(rh, seed)
+    worst = 0.0
+    for frame in range(2):   # the second frame reuses static maps and moves nothing: it must equal the first
+        a, la = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        b, lb = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        exact = [("depth", ro.read_depth(), rh.read_depth()), ("visibility", ro.read_visibility(), rh.read_visibility())]
+        readers = [(f"cascade {i}", lambda r, i=i: r.read_directional_shadow(i)) for i in range(4)]
+        readers += [(f"point {slot}/{face}", lambda r, slot=slot, face=face: r.read_point_shadow(slot, face))
+                    for slot in range(st["point_shadow_map_count"]) for face in range(6)]
+        for name, read in readers:
+            got = []
+            for r in (ro, rh):   # a map that does not exist (no lights set, a slot no light has taken) cannot be read: on both sides or on neither
+                try:
+                    got.append(read(r))
+                except Exception:
+                    got.append(None)
+            if (got[0] is None) != (got[1] is None):
+                print(f"seed {seed} frame {frame}: {name} readable on one side only")
+                return False, 1.0
+            if got[0] is not None:
+                exact.append((name, got[0], got[1]))
+        for name, x, y in exact:
+            if not np.array_equal(x, y):
+                print(f"seed {seed} frame {frame}: {name} differs in {int((x != y).sum())} of {x.size} values ({W}x{H} msaa {msaa} {st})")
+                return False, 1.0
+        so, sh = ro.frame_stats(), rh.frame_stats()
+        # (only the first frame: the library does not redraw shadow views that nothing changed, the checker does)
+        if frame == 0 and (so.triangle_instances, so.triangles_binned, so.views) != (sh.triangle_instances, sh.triangles_binned, sh.views):
+            print(f"seed {seed} frame {frame}: counters differ {so.triangle_instances, so.triangles_binned, so.views} / {sh.triangle_instances, sh.triangles_binned, sh.views}")
+            return False, 1.0
+        diff = np.abs(a.astype(np.int32) - b.astype(np.int32)).max(-1)
+        if float((diff > 1).mean()) > 0.001:
+            print(f"  seed {seed} frame {frame}: {int((diff > 1).sum())} of {diff.size} pixels apart, largest step {int(diff.max())}; avg log luminance {la} / {lb}; "
+                  f"exposure {ro.frame_stats().exposure} / {rh.frame_stats().exposure}; {W}x{H} msaa {msaa} {st}")
+        worst = max(worst, float((diff > 1).mean()))
+    ro.close(); rh.close()
+    return True, worst
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    orc_capi = orc.capi()
+    hip_capi = orc_capi if os.environ.get("FUZZ_SELF") else load_hip_capi()  # FUZZ_SELF=1: the checker against itself, to try the script without a GPU
+    off = []
+    for seed in range(first, first + count):
+        ok, share = one(seed, orc_capi, hip_capi)
+        if not ok:
+            sys.exit(1)
+        off.append(share)
+        print(f"seed {seed}: exact images equal, {share * 1e3:.2f} per thousand pixels of the frame further apart than one step", flush=True)
+    print(f"{count} scenes: worst {max(off) * 1e3:.2f} per thousand, mean {np.mean(off) * 1e3:.3f}")
+
+
+if __name__ == "__main__":
+    main()
