@@ -18,3 +18,13 @@ def test_random_scenes(orc_capi, hip_capi):
         assert share <= 0.002, (seed, share)
         worst = max(worst, share)
     print("largest share of pixels further apart than one step:", worst)
+
+
+def test_random_images_through_the_tail(orc_capi, hip_capi):
+    """tools/fuzz_post.py: bloom chain, tonemap and luminance on images from 1 x 1 upwards, dark to 65504, then with
+    infinities and NaNs in them: bloom levels bit for bit, the output within one step."""
+    from tools import fuzz_post as P
+    for seed in range(0, 80):
+        assert P.one(seed, orc_capi, hip_capi), seed
+    for seed in range(1000, 1040):
+        assert P.one(seed, orc_capi, hip_capi, special=True), seed
