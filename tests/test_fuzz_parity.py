@@ -28,3 +28,11 @@ def test_random_images_through_the_tail(orc_capi, hip_capi):
         assert P.one(seed, orc_capi, hip_capi), seed
     for seed in range(1000, 1040):
         assert P.one(seed, orc_capi, hip_capi, special=True), seed
+
+
+def test_random_environments(orc_capi, hip_capi):
+    """tools/fuzz_bake.py: faces from 1 x 1 upwards or a panorama, dim skies to 60000-nit suns, through the bakes: every
+    cube and every generated BRDF table bit for bit."""
+    from tools import fuzz_bake as K
+    for seed in range(0, 8):
+        assert K.one(seed, orc_capi, hip_capi), seed
