@@ -3,6 +3,7 @@
   python tools/fuzz_parity.py [first_seed] [count] [frames]
 
 Every seed makes one scene: a few triangle soups (small, huge, crossing the near plane, slivers, repeated vertices),
+some of them skinned,
 materials with random alpha modes, wrap modes, filters, image sizes and formats, up to six point lights of which some
 cast shadows, a random camera, frame size and sample count. Depth, visibility, cascades and point-light faces must be
 equal bit for bit; the 8-bit frame is compared pixel by pixel and the share of pixels further apart than one step is
@@ -80,7 +81,7 @@ def random_images(rng):
 
 
 def build(r, seed):
-    """Returns the meshes that may move: [(mesh id, model matrix)]."""
+    """Returns the meshes that may move: [(mesh id, model matrix, number of joints or 0)]."""
     rng = np.random.default_rng(seed)
     big = seed >= BIG_FROM
     n_prims = int(rng.integers(8, 40)) if big else int(rng.integers(1, 6))
@@ -102,9 +103,25 @@ def build(r, seed):
                                    alpha_mode=mode, alpha_cutoff=float(rng.uniform(0.2, 0.8)))
         model = scenes.translation(*rng.normal(0, 1.0, 3)) @ scenes.rotation_y(float(rng.uniform(0, 6.28))) @ scenes.rotation_x(float(rng.uniform(0, 6.28)))
         is_static = bool(rng.random() < 0.6)
+        if rng.random() < 0.25:
+            # a skinned primitive: 2-6 joints, four influences per vertex (some with zero weight, weights not normalised
+            # in a tenth of the cases), joint indices and weights in a random storage type
+            n_joints = int(rng.integers(2, 7))
+            nv = geo.pos.shape[0]
+            joints = rng.integers(0, n_joints, (nv, 4))
+            weights = rng.random((nv, 4)) * (rng.random((nv, 4)) < 0.7)
+            weights[:, 0] += 0.05
+            if rng.random() < 0.9:
+                weights /= weights.sum(-1, keepdims=True)
+            prim = scenes.upload_skinned_primitive(r, geo, joints, weights, mat, joint_type=int(rng.choice([B.UINT8, B.UINT16])),
+                                                   weight_type=int(rng.choice([B.FLOAT, B.UINT8, B.UINT16])))
+            mesh = r.add_mesh([prim], model=np.ascontiguousarray(model.T, np.float32), is_static=False)
+            r.set_mesh_joints(mesh, joint_palette(rng, n_joints))
+            movable.append((mesh, model, n_joints))
+            continue
         mesh = r.add_mesh([scenes.upload_primitive(r, geo, mat, B.UINT32)], model=np.ascontiguousarray(model.T, np.float32), is_static=is_static)
         if not is_static:
-            movable.append((mesh, model))
+            movable.append((mesh, model, 0))
     if rng.random() < 0.9:
         r.set_brdf_lut(scenes.brdf_lut(16, 16))
         r.set_environment_map(scenes.sky_faces(int(rng.choice([4, 16])), seed=seed))
@@ -118,13 +135,24 @@ def build(r, seed):
     return movable
 
 
+def joint_palette(rng, n):
+    """n joint matrices near the identity, as the C ABI takes them."""
+    out = []
+    for _ in range(n):
+        m = scenes.translation(*rng.normal(0, 0.3, 3)) @ scenes.rotation_y(float(rng.normal(0, 0.4))) @ scenes.rotation_x(float(rng.normal(0, 0.4)))
+        out.append(m.T)
+    return np.ascontiguousarray(np.stack(out), np.float32)
+
+
 def change(r, movable, seed, frame):
     """What happens between two frames of a seed: any of a moved mesh, a moved camera, other lights - or nothing."""
     rng = np.random.default_rng(seed * 1000 + frame)
     if movable and rng.random() < 0.6:
-        mesh, model = movable[int(rng.integers(0, len(movable)))]
+        mesh, model, n_joints = movable[int(rng.integers(0, len(movable)))]
         moved = scenes.translation(*rng.normal(0, 0.5, 3)) @ model @ scenes.rotation_y(float(rng.uniform(0, 1.0)))
         r.set_mesh_transform(mesh, np.ascontiguousarray(moved.T, np.float32))
+        if n_joints:
+            r.set_mesh_joints(mesh, joint_palette(rng, n_joints))
     if rng.random() < 0.5:
         r.set_camera(position=tuple(rng.normal(0, 3.0, 3) + np.array([0, 0, 4.0])), euler=(float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.8, 0.8)), 0.0))
     if rng.random() < 0.4:
