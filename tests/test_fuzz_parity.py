@@ -36,3 +36,11 @@ def test_random_environments(orc_capi, hip_capi):
     from tools import fuzz_bake as K
     for seed in range(0, 8):
         assert K.one(seed, orc_capi, hip_capi), seed
+
+
+def test_frames_in_flight_equal_frames_one_at_a_time(hip_capi):
+    """tools/fuzz_pipeline.py: random scenes with changes between frames, rendered into host memory frame by frame and
+    into device buffers with nothing waited for in between: the same bytes."""
+    from tools import fuzz_pipeline as P
+    for seed in range(0, 20):
+        assert P.one(seed, hip_capi, 6), seed
