@@ -25,6 +25,7 @@ from renderer_amd.api import Renderer, default_settings, load_hip_capi  # noqa: 
 
 
 BIG_FROM = 100000   # seeds from here on: larger frames, more primitives, more triangles, sometimes an RGBA16F output
+WIDE_FROM = 50000   # seeds from here on: also 1-4 cascades, up to 8 cubes, other gammas, all three exposure modes, orthographic cameras
 
 
 def soup(rng, kind, n):
@@ -130,8 +131,12 @@ def build(r, seed):
     if rng.random() < 0.9:
         r.set_lights(lights, scenes.default_directional_light())
         r.fuzz_casters = sum(1 for l in lights if l[2])
+    if seed >= WIDE_FROM and rng.random() < 0.3:
+        r.set_camera(position=tuple(rng.normal(0, 3.0, 3) + np.array([0, 0, 6.0])), euler=(float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.8, 0.8)), 0.0),
+                     near=0.1, far=float(rng.choice([20.0, 60.0])), fov_or_height=float(rng.uniform(2.0, 12.0)), cam_type=B.CAMERA_ORTHOGRAPHIC)
+        return movable
     r.set_camera(position=tuple(rng.normal(0, 3.0, 3) + np.array([0, 0, 4.0])), euler=(float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.2, 0.2))),
-                 near=float(rng.choice([0.05, 0.1, 0.5])), far=float(rng.choice([20.0, 60.0, 200.0])))
+                 near=float(rng.choice([0.05, 0.1, 0.5])), far=float(rng.choice([20.0, 60.0, 200.0])), fov_or_height=float(np.radians(rng.choice([25.0, 40.0, 75.0]))))
     return movable
 
 
@@ -169,6 +174,13 @@ def one(seed, orc_capi, hip_capi, frames=2):
     msaa = int(rng.choice([1, 4]))
     st = dict(msaa=msaa, hdr_output_enabled=int(seed >= BIG_FROM and rng.random() < 0.3), directional_shadow_map_resolution=int(rng.choice([64, 200, 512])), point_shadow_map_resolution=int(rng.choice([16, 50, 128])),
               point_shadow_map_count=int(rng.integers(0, 4)), dynamic_shadows_enabled=int(rng.random() < 0.8))
+    if seed >= WIDE_FROM:   # every setting and every frame parameter
+        st.update(directional_shadow_cascade_levels=int(rng.integers(1, 5)), point_shadow_map_count=int(rng.integers(0, 9)),
+                  gamma=float(rng.choice([1.0, 2.2, 2.6])), exposure_bias=float(rng.uniform(-2, 2)))
+    frame_kw = dict(exposure_mode=1, temporal_luminance=0.5)
+    if seed >= WIDE_FROM:
+        frame_kw = [dict(exposure_mode=0, delta_time=float(rng.uniform(0.001, 0.5))), dict(exposure_mode=1, temporal_luminance=float(rng.uniform(0.01, 4.0))),
+                    dict(exposure_mode=2, exposure=float(rng.uniform(-3, 3)))][int(rng.integers(0, 3))]
     ro = Renderer(orc_capi, W, H, default_settings(**st), keep_intermediates=True)
     rh = Renderer(hip_capi, W, H, default_settings(**st), keep_intermediates=True)
     mo, mh = build(ro, seed), build(rh, seed)
@@ -176,8 +188,8 @@ def one(seed, orc_capi, hip_capi, frames=2):
     for frame in range(frames):   # the second frame reuses static maps and moves nothing; from the third on things change
         if frame >= 2:
             change(ro, mo, seed, frame); change(rh, mh, seed, frame)
-        a, la = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
-        b, lb = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        a, la = ro.render_frame(**frame_kw)
+        b, lb = rh.render_frame(**frame_kw)
         exact = [("depth", ro.read_depth(), rh.read_depth()), ("visibility", ro.read_visibility(), rh.read_visibility())]
         readers = [(f"cascade {i}", lambda r, i=i: r.read_directional_shadow(i)) for i in range(4)]
         readers += [(f"point {slot}/{face}", lambda r, slot=slot, face=face: r.read_point_shadow(slot, face))

@@ -27,7 +27,8 @@ def image(rng, W, H, special):
         a[ys[0], xs[0], int(rng.integers(0, 3))] = np.inf
         a[ys[1], xs[1], int(rng.integers(0, 3))] = np.nan
     a[..., 3] = 1.0
-    return np.minimum(a, 65504.0).astype(np.float16).astype(np.float32) if not special else a.astype(np.float16).astype(np.float32)
+    with np.errstate(over="ignore"):   # values beyond binary16 become infinities, on purpose, in the special images
+        return np.minimum(a, 65504.0).astype(np.float16).astype(np.float32) if not special else a.astype(np.float16).astype(np.float32)
 
 
 def one(seed, orc_capi, hip_capi, special=False):
