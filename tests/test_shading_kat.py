@@ -211,6 +211,44 @@ def test_mip_mapped_textures_and_shadowed_point_lights(orc_capi, msaa):
     print(check_detail(orc_capi, msaa))
 
 
+def check_jittered(capi, seed, monkeypatch):
+    """The textured scene from another camera, under other lights, through another variant of its materials: the same
+    float64 expectations, so that the known answers do not hang on one view of one arrangement."""
+    rng = np.random.default_rng(seed)
+    cam = dict(K.CAMERA)
+    cam["position"] = tuple(np.asarray(cam["position"]) + rng.uniform(-0.6, 0.6, 3))
+    cam["euler"] = tuple(np.asarray(cam["euler"]) + np.array([rng.uniform(-0.08, 0.08), rng.uniform(-0.15, 0.15), 0.0]))
+    cam["fov"] = float(np.float32(np.radians(rng.uniform(32.0, 52.0))))
+    lights = [(tuple(np.asarray(p) + rng.uniform(-0.7, 0.7, 3)), tuple(np.asarray(i) * rng.uniform(0.5, 1.5, 3)), cast) for p, i, cast in K.DETAIL_LIGHTS]
+    monkeypatch.setattr(K, "CAMERA", cam)
+    monkeypatch.setattr(K, "DETAIL_LIGHTS", lights)
+    variant = ["detail", "filters", "float"][seed % 3]
+    msaa = [1, 4][(seed // 3) % 2]
+    W, H = int(rng.integers(150, 260)), int(rng.integers(90, 150))
+    r = _renderer(capi, W, H, msaa)
+    built = K.build(r, K.linear_environment(32), variant=variant)
+    r.render_frame(exposure_mode=2, exposure=0.0)
+    got = r.read_hdr().astype(np.float64)
+    det = {}
+    want, valid = K.expected_hdr(r, W, H, margin=0.02 if msaa == 1 else 1.0, variant=variant, built=built, details=det)
+    n_frag = int((valid & (det["prim"] >= 0)).sum())
+    assert n_frag >= 1500, f"only {n_frag} shaded fragments are pinned"
+    _assert_close(got, want, valid, rtol=1.5e-3, atol=2e-4, what=f"pbr.frag, {variant} scene, seed {seed}, msaa {msaa}, {W}x{H}")
+    r.close()
+    return n_frag
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_other_views_of_the_textured_scene(orc_capi, seed, monkeypatch):
+    print(check_jittered(orc_capi, seed, monkeypatch))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_other_views_of_the_textured_scene_hip(hip_capi, seed, monkeypatch):
+    print(check_jittered(hip_capi, seed, monkeypatch))
+
+
 @pytest.mark.parametrize("msaa", [1, 4])
 def test_nearest_sampler_filters(orc_capi, msaa):
     """The Sampler's magFilter / minFilter / mipmapFilter (VulkanRenderer.cpp:363-385) by the Vulkan rules, in float64."""
