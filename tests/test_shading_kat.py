@@ -220,10 +220,12 @@ def check_jittered(capi, seed, monkeypatch):
     cam["euler"] = tuple(np.asarray(cam["euler"]) + np.array([rng.uniform(-0.08, 0.08), rng.uniform(-0.15, 0.15), 0.0]))
     cam["fov"] = float(np.float32(np.radians(rng.uniform(32.0, 52.0))))
     lights = [(tuple(np.asarray(p) + rng.uniform(-0.7, 0.7, 3)), tuple(np.asarray(i) * rng.uniform(0.5, 1.5, 3)), cast) for p, i, cast in K.DETAIL_LIGHTS]
+    plain = [(tuple(np.asarray(p) + rng.uniform(-0.7, 0.7, 3)), tuple(np.asarray(i) * rng.uniform(0.5, 1.5, 3))) for p, i in K.POINT_LIGHTS]
     monkeypatch.setattr(K, "CAMERA", cam)
     monkeypatch.setattr(K, "DETAIL_LIGHTS", lights)
-    variant = ["detail", "filters", "float"][seed % 3]
-    msaa = [1, 4][(seed // 3) % 2]
+    monkeypatch.setattr(K, "POINT_LIGHTS", plain)
+    variant = ["detail", "filters", "float", "base"][seed % 4]   # "base": 1x1 textures, five lights without maps, MASK and BLEND quads
+    msaa = [1, 4][(seed // 4) % 2]
     W, H = int(rng.integers(150, 260)), int(rng.integers(90, 150))
     r = _renderer(capi, W, H, msaa)
     built = K.build(r, K.linear_environment(32), variant=variant)
@@ -232,13 +234,13 @@ def check_jittered(capi, seed, monkeypatch):
     det = {}
     want, valid = K.expected_hdr(r, W, H, margin=0.02 if msaa == 1 else 1.0, variant=variant, built=built, details=det)
     n_frag = int((valid & (det["prim"] >= 0)).sum())
-    assert n_frag >= 1500, f"only {n_frag} shaded fragments are pinned"
+    assert n_frag >= 1200, f"only {n_frag} shaded fragments are pinned"
     _assert_close(got, want, valid, rtol=1.5e-3, atol=2e-4, what=f"pbr.frag, {variant} scene, seed {seed}, msaa {msaa}, {W}x{H}")
     r.close()
     return n_frag
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_other_views_of_the_textured_scene(orc_capi, seed, monkeypatch):
     print(check_jittered(orc_capi, seed, monkeypatch))
 
