@@ -129,11 +129,10 @@ RDR_DEV v2f v2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 RDR_DEV v2f v2s(float a) { return v2(a, a); }
 // brdf_eval below for two lights at once, one per vector component: the sums, products and fused multiply-adds are
 // two-component instructions, only the reciprocals, square roots and min / max work on one component at a time.
-RDR_DEV void brdf_eval2(const BrdfFrag& f, v2f LL, v2f NL, v2f VL, v2f& r, v2f& g, v2f& b) {
+RDR_DEV void brdf_eval2(const BrdfFrag& f, v2f t, v2f omLL, v2f NL, v2f& r, v2f& g, v2f& b) {
 #pragma clang fp contract(fast)
-    const v2f t = 2.0f * VL + (1.0f + LL);
     const v2f rs = v2(__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y));
-    v2f NdotH = (f.NV + NL) * rs, HdotV = (1.0f + VL) * rs;
+    v2f NdotH = (f.NV + NL) * rs, HdotV = (0.5f * (t + omLL)) * rs;
     NdotH = v2(clampf(NdotH.x, 0.0f, 1.0f), clampf(NdotH.y, 0.0f, 1.0f));
     HdotV = v2(clampf(HdotV.x, 0.0f, 1.0f), clampf(HdotV.y, 0.0f, 1.0f));
     v2f dd = NdotH * NdotH * f.a2m1 + 1.0f;
@@ -159,14 +158,17 @@ RDR_DEV void brdf_eval2(const BrdfFrag& f, v2f LL, v2f NL, v2f VL, v2f& r, v2f& 
     b = ((f.kdiff.z - Fz * f.kdiff.z) + spec * Fz) * NdotL;
 }
 // BRDF(1, L, ...) of pbr.frag: the outgoing radiance per unit of light radiance, cosine term included. L need not be
-// normalised (the reference passes the raw light vector for lights without a shadow map, pbr.frag:157-158): LL = L.L,
-// NL = N.L, VL = V.L. The half vector never materialises: with |V| = 1, |V + L|^2 = 1 + 2 V.L + L.L,
-// N.H = (N.V + N.L) / |V + L| and H.V = (1 + V.L) / |V + L|.
-RDR_DEV F3 brdf_eval(const BrdfFrag& f, float LL, float NL, float VL) {
+// normalised (the reference passes the raw light vector for lights without a shadow map, pbr.frag:157-158):
+// t = |V + L|^2, omLL = 1 - L.L, NL = N.L. The half vector itself never materialises: with |V| = 1,
+// N.H = (N.V + N.L) / |V + L| and H.V = (1 + V.L) / |V + L| with 1 + V.L = (t + 1 - L.L) / 2. Its length does, from the
+// components of V + L: where the
+// light is nearly opposite the view direction (the grazing highlight of a surface seen against the light) 1 + 2 V.L + L.L
+// cancels to a few float steps while the sum of the vectors keeps its digits, and N.H near 1 needs them.
+RDR_DEV F3 brdf_eval(const BrdfFrag& f, float t, float omLL, float NL) {
 #pragma clang fp contract(fast)
-    const float rs = __builtin_amdgcn_rsqf(2.0f * VL + (1.0f + LL));
+    const float rs = __builtin_amdgcn_rsqf(t);
     const float NdotH = clampf((f.NV + NL) * rs, 0.0f, 1.0f);
-    const float HdotV = clampf((1.0f + VL) * rs, 0.0f, 1.0f);
+    const float HdotV = clampf((0.5f * (t + omLL)) * rs, 0.0f, 1.0f);
     float dd = NdotH * NdotH * f.a2m1 + 1.0f;
     dd = kPI * dd * dd;
     const float NL1 = fmaxf(NL, 1e-3f);
@@ -495,7 +497,6 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const v2f Lx = v2(pl.px[0], pl.px[1]) - P.x, Ly = v2(pl.py[0], pl.py[1]) - P.y, Lz = v2(pl.pz[0], pl.pz[1]) - P.z;
         const v2f d2 = __builtin_elementwise_fma(Lz, Lz, __builtin_elementwise_fma(Ly, Ly, Lx * Lx));  // distance^2
         const v2f nl = __builtin_elementwise_fma(v2s(N.z), Lz, __builtin_elementwise_fma(v2s(N.y), Ly, N.x * Lx));
-        const v2f vl = __builtin_elementwise_fma(v2s(V.z), Lz, __builtin_elementwise_fma(v2s(V.y), Ly, V.x * Lx));
         // radiance = intensity / distance^2; skipped when its largest channel is <= 1e-3 (pbr.frag:133)
         const bool lit[2] = {!(fmaxf(pl.ix[0], fmaxf(pl.iy[0], pl.iz[0])) <= 1e-3f * d2.x), !(fmaxf(pl.ix[1], fmaxf(pl.iy[1], pl.iz[1])) <= 1e-3f * d2.y)};
         float sh[2];
@@ -523,7 +524,14 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const bool unit0 = (pl.flags[0] & 3u) == 3u, unit1 = (pl.flags[1] & 3u) == 3u;
         const v2f ls = v2(unit0 ? __builtin_amdgcn_rsqf(d2.x) : 1.0f, unit1 ? __builtin_amdgcn_rsqf(d2.y) : 1.0f);
         v2f r, g, b;
-        brdf_eval2(bf, v2(unit0 ? 1.0f : d2.x, unit1 ? 1.0f : d2.y), nl * ls, vl * ls, r, g, b);
+        // |V + L|^2 from the components of the sum (see brdf_eval), one component at a time
+        v2f hh, hc = __builtin_elementwise_fma(Lx, ls, v2s(V.x));
+        hh = hc * hc;
+        hc = __builtin_elementwise_fma(Ly, ls, v2s(V.y));
+        hh = __builtin_elementwise_fma(hc, hc, hh);
+        hc = __builtin_elementwise_fma(Lz, ls, v2s(V.z));
+        hh = __builtin_elementwise_fma(hc, hc, hh);
+        brdf_eval2(bf, hh, v2(unit0 ? 0.0f : 1.0f - d2.x, unit1 ? 0.0f : 1.0f - d2.y), nl * ls, r, g, b);
 #if RDR_BRDF_ONE_RCP
         const v2f att = v2(unit0 ? ls.x * ls.x : fast_rcp(d2.x), unit1 ? ls.y * ls.y : fast_rcp(d2.y));  // 1 / distance^2
         const v2f w = v2(on0 ? att.x * sh[0] : 0.0f, on1 ? att.y * sh[1] : 0.0f);  // attenuation x shadow
@@ -555,7 +563,11 @@ RDR_DEV void shade_fragment(const DFrame& fr, const DPointLight* __restrict__ li
         const float shadowTest = shadow_pcf(as_global(fr.dir_shadow) + (size_t)layer * (res + 4) * (res + 4), res, ls0, ls1, ls2,
                                                 (RDR_DIAG_COALESCE & 8) ? RDR_DIAG_ZERO(fr) : ~0u);
         if (shadowTest > 1e-3f) {
-            const F3 r = brdf_eval(bf, 1.0f, dir_nl, dot3f(V, dirL));
+            // |V + L|^2 accumulated component by component (one temporary: this is where the kernel's register count peaks)
+            float hc = V.x + dirL.x, hh = hc * hc;
+            hc = V.y + dirL.y; hh = fmaf(hc, hc, hh);
+            hc = V.z + dirL.z; hh = fmaf(hc, hc, hh);
+            const F3 r = brdf_eval(bf, hh, 0.0f, dir_nl);
             Lo = Lo + f3(r.x * (fr.dir_I[0] * shadowTest), r.y * (fr.dir_I[1] * shadowTest), r.z * (fr.dir_I[2] * shadowTest));
         }
     }

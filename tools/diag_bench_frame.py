@@ -79,3 +79,25 @@ if len(ys):
     for jj in (j0, j0 + 1):
         row = [float(fmap[min(max(jj, 0), res - 1), min(max(ii, 0), res - 1)]) for ii in (i0, i0 + 1)]
         print("   ", [f"{d_:.8f} ({'lit' if ref <= d_ else 'shadowed'}, eye distance {0.1 * 100.0 / (100.0 - d_ * 99.9):.5f})" for d_ in row])
+
+# the neighbourhood of the worst pixel under `bad_light` alone, both sides (red channel of the colour image)
+if len(ys):
+    for r in (ro, rh):
+        r.set_lights([lights[bad_light]], scenes.default_directional_light())
+    ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    wo, wh = ro.read_hdr()[y - 4:y + 5, x - 5:x + 6, 0], rh.read_hdr()[y - 4:y + 5, x - 5:x + 6, 0]
+    np.set_printoptions(linewidth=200, precision=3, suppress=True)
+    print("checker:\n", wo)
+    print("library:\n", wh)
+
+# the same with the light's shadow switched off: is it the look-up or the BRDF?
+if len(ys):
+    nl = (lights[bad_light][0], lights[bad_light][1], False)
+    for r in (ro, rh):
+        r.set_lights([nl], scenes.default_directional_light())
+    ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+    wo, wh = ro.read_hdr()[y - 4:y + 5, x - 5:x + 6, 0], rh.read_hdr()[y - 4:y + 5, x - 5:x + 6, 0]
+    print("without its shadow map, checker:\n", wo)
+    print("without its shadow map, library:\n", wh)
