@@ -221,6 +221,23 @@ def check_jittered(capi, seed, monkeypatch):
     cam["fov"] = float(np.float32(np.radians(rng.uniform(32.0, 52.0))))
     lights = [(tuple(np.asarray(p) + rng.uniform(-0.7, 0.7, 3)), tuple(np.asarray(i) * rng.uniform(0.5, 1.5, 3)), cast) for p, i, cast in K.DETAIL_LIGHTS]
     plain = [(tuple(np.asarray(p) + rng.uniform(-0.7, 0.7, 3)), tuple(np.asarray(i) * rng.uniform(0.5, 1.5, 3))) for p, i in K.POINT_LIGHTS]
+    if seed >= 1000:
+        # against the light: the camera low over the ground, the lights low on the far side of the scene, so that the ground
+        # between them is seen at grazing angles with V.L near -1 (forward highlights, where N.H is formed from nearly
+        # opposite vectors)
+        cam["position"] = (float(rng.uniform(-2.0, 2.0)), float(rng.uniform(0.35, 1.0)), float(rng.uniform(6.0, 8.0)))
+        cam["euler"] = (float(rng.uniform(-0.12, -0.02)), float(rng.uniform(-0.15, 0.15)), 0.0)
+        far_side = lambda: (float(rng.uniform(-4.0, 4.0)), float(rng.uniform(0.2, 1.2)), float(rng.uniform(-22.0, -6.0)))  # noqa: E731
+        lights = [(far_side(), tuple(np.asarray(i) * rng.uniform(2.0, 8.0)), cast) for p, i, cast in K.DETAIL_LIGHTS]
+        plain = [(far_side(), tuple(np.asarray(i) * rng.uniform(2.0, 8.0))) for p, i in K.POINT_LIGHTS]
+        original_prims = K.prims
+
+        def glossy_prims(variant="base"):   # roughness factors quartered: highlights a few pixels wide
+            opaque, blended = original_prims(variant)
+            for p in opaque + blended:
+                p.mat["roughness"] = float(np.float32(p.mat["roughness"] * 0.25))
+            return opaque, blended
+        monkeypatch.setattr(K, "prims", glossy_prims)
     monkeypatch.setattr(K, "CAMERA", cam)
     monkeypatch.setattr(K, "DETAIL_LIGHTS", lights)
     monkeypatch.setattr(K, "POINT_LIGHTS", plain)
@@ -234,8 +251,9 @@ def check_jittered(capi, seed, monkeypatch):
     det = {}
     want, valid = K.expected_hdr(r, W, H, margin=0.02 if msaa == 1 else 1.0, variant=variant, built=built, details=det)
     n_frag = int((valid & (det["prim"] >= 0)).sum())
-    assert n_frag >= 1200, f"only {n_frag} shaded fragments are pinned"
-    _assert_close(got, want, valid, rtol=1.5e-3, atol=2e-4, what=f"pbr.frag, {variant} scene, seed {seed}, msaa {msaa}, {W}x{H}")
+    assert n_frag >= (800 if seed >= 1000 else 1200), f"only {n_frag} shaded fragments are pinned"
+    # (against the light with glossy materials the float32 evaluation of a narrow lobe is itself worth 2e-3 on single pixels)
+    _assert_close(got, want, valid, rtol=2.5e-3 if seed >= 1000 else 1.5e-3, atol=2e-4, what=f"pbr.frag, {variant} scene, seed {seed}, msaa {msaa}, {W}x{H}")
     r.close()
     return n_frag
 
@@ -243,6 +261,19 @@ def check_jittered(capi, seed, monkeypatch):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_other_views_of_the_textured_scene(orc_capi, seed, monkeypatch):
     print(check_jittered(orc_capi, seed, monkeypatch))
+
+
+@pytest.mark.parametrize("seed", [1000, 1001])
+def test_grazing_highlights_against_the_light(orc_capi, seed, monkeypatch):
+    """Camera low over the ground, lights low on the far side, glossy materials: V.L near -1, where the length of the half
+    vector must come from the sum of the vectors and not from 1 + 2 V.L + L.L."""
+    print(check_jittered(orc_capi, seed, monkeypatch))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(1000, 1012)))
+def test_grazing_highlights_against_the_light_hip(hip_capi, seed, monkeypatch):
+    print(check_jittered(hip_capi, seed, monkeypatch))
 
 
 @pytest.mark.gpu
