@@ -250,3 +250,20 @@ def test_benchmark_frame_against_the_checker_at_full_size(orc_capi, hip_capi):
     so, sh = ro.frame_stats(), rh.frame_stats()
     assert (so.triangle_instances, so.triangles_binned, so.views) == (sh.triangle_instances, sh.triangles_binned, sh.views)
     ro.close(); rh.close()
+
+
+def test_frames_and_shadow_maps_larger_than_the_benchmark(orc_capi, hip_capi):
+    """Beyond the benchmark's size: 7680x4320 at 4 samples per pixel with 4096^2 cascades and 1024^2 cube faces (the hall at
+    half detail, its sixteen lights), and a small frame with the largest cascades the settings accept (16384^2; 22 million
+    (tile, triangle) pairs, the multi-kernel scan and sort). tools/max_size_check.py goes on to 16384x16384 at 4 samples
+    (2^30 of them) and 8192^2 cube faces, which take the checker half a minute a frame."""
+    for (W, H, msaa, dir_res, point_res) in ((7680, 4320, 4, 4096, 1024), (512, 512, 1, 16384, 256)):
+        ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, msaa=msaa, directional_shadow_map_resolution=dir_res, point_shadow_map_resolution=point_res)
+        for r in (ro, rh):
+            scenes.sponza_like(r, tex_size=256, detail=0.5)
+            r.set_camera(position=(-6.5, 2.2, 0.2), euler=(-0.2, -1.0, 0.0))
+        compare_frame(ro, rh)
+        for slot in (0, 5):
+            for face in (1, 3):
+                assert np.array_equal(ro.read_point_shadow(slot, face), rh.read_point_shadow(slot, face)), (W, slot, face)
+        ro.close(); rh.close()

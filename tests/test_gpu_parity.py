@@ -401,3 +401,26 @@ def test_float_output_frame(orc_capi, hip_capi, size):
     pp_h, _ = rh.post_process(hdr, rh.frame_stats().exposure)
     assert np.array_equal(pp_h.view(np.uint16), out_h.view(np.uint16))
     ro.close(); rh.close()
+
+
+@pytest.mark.parametrize("case", [(1, 1, 1, 1, 1), (1, 1, 4, 7, 3), (2, 3, 4, 16, 16), (16, 16, 1, 33, 17), (15, 33, 4, 64, 32)])
+def test_smallest_frames_and_shadow_maps(orc_capi, hip_capi, case):
+    """The other end of the sizes: a frame of one pixel, frames smaller than one 16-pixel tile, shadow maps of one texel
+    and of odd sizes (the hall at a tenth of its detail, all sixteen lights), two frames each."""
+    W, H, msaa, dir_res, point_res = case
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, msaa=msaa, directional_shadow_map_resolution=dir_res, point_shadow_map_resolution=point_res)
+    for r in (ro, rh):
+        scenes.sponza_like(r, tex_size=16, env_res=8, detail=0.1)
+    for cam in (((-11.0, 2.2, 0.6), (-0.05, -1.45, 0.0)), ((-3.0, 1.0, 0.4), (-0.4, 0.6, 0.0))):
+        for r in (ro, rh):
+            r.set_camera(position=cam[0], euler=cam[1])
+        a, la = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        b, lb = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        assert np.array_equal(ro.read_depth(), rh.read_depth()) and np.array_equal(ro.read_visibility(), rh.read_visibility())
+        for c in range(4):
+            assert np.array_equal(ro.read_directional_shadow(c), rh.read_directional_shadow(c)), c
+        for slot in range(8):
+            for face in range(6):
+                assert np.array_equal(ro.read_point_shadow(slot, face), rh.read_point_shadow(slot, face)), (slot, face)
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1 and abs(la - lb) < 2e-3
+    ro.close(); rh.close()
