@@ -424,3 +424,32 @@ def test_smallest_frames_and_shadow_maps(orc_capi, hip_capi, case):
                 assert np.array_equal(ro.read_point_shadow(slot, face), rh.read_point_shadow(slot, face)), (slot, face)
         assert np.abs(a.astype(int) - b.astype(int)).max() <= 1 and abs(la - lb) < 2e-3
     ro.close(); rh.close()
+
+
+@pytest.mark.parametrize("cubes", [3, 8, 64])
+def test_many_point_lights(orc_capi, hip_capi, cubes):
+    """The reference's light list has no fixed length (pbr.frag:123 loops over the storage buffer's length): 67 lights, an
+    odd count, 12 of them casting shadows, with fewer cube maps than casters (the nearest get them,
+    VulkanRendererShadow.cpp:280-298), as many as the default, and more than there are casters."""
+    W, H = 320, 200
+    ro, rh = hp.make_pair(orc_capi, hip_capi, W, H, msaa=4, directional_shadow_map_resolution=512, point_shadow_map_resolution=128,
+                          point_shadow_map_count=cubes)
+    rng = np.random.default_rng(5)
+    lights = [((float(rng.uniform(-12, 12)), float(rng.uniform(0.4, 5.0)), float(rng.uniform(-5, 5))), tuple(float(v) for v in rng.uniform(2.0, 30.0, 3)), k % 6 == 0)
+              for k in range(67)]
+    assert sum(l[2] for l in lights) == 12
+    for r in (ro, rh):
+        scenes.sponza_like(r, tex_size=32, env_res=16, detail=0.2)
+        r.set_lights(lights, scenes.default_directional_light())
+    for cam in (((-11.0, 2.2, 0.6), (-0.05, -1.45, 0.0)), ((5.0, 1.5, -0.5), (-0.1, 1.2, 0.0))):  # the second camera reassigns the cubes
+        for r in (ro, rh):
+            r.set_camera(position=cam[0], euler=cam[1])
+        a, la = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        b, lb = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+        assert np.array_equal(ro.read_depth(), rh.read_depth()) and np.array_equal(ro.read_visibility(), rh.read_visibility())
+        for slot in range(min(cubes, 12)):
+            for face in range(6):
+                assert np.array_equal(ro.read_point_shadow(slot, face), rh.read_point_shadow(slot, face)), (slot, face)
+        hp.assert_image_close(a, b)
+        assert abs(la - lb) < 2e-3
+    ro.close(); rh.close()
