@@ -66,7 +66,7 @@ def shade_flops_per_px(n_point_lights):
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` (FETCH_SIZE + WRITE_SIZE) from the PMC passes committed under profiles/
+    """HBM bytes per launch of `kernel` (2 x FETCH_SIZE + WRITE_SIZE) from the PMC passes committed under profiles/
     (tools/profile_gpu.sh + tools/pmc_summary.py, the headline bench command); None when no summary is there."""
     import glob
     import re
@@ -78,8 +78,12 @@ def measured_traffic(kernel):
         m_f = re.search(r"FETCH_SIZE\s+n=\d+\s+mean=([0-9.e+]+)", block.group(0))
         m_w = re.search(r"WRITE_SIZE\s+n=\d+\s+mean=([0-9.e+]+)", block.group(0))
         if m_f and m_w:
-            best = {"bytes": (float(m_f.group(1)) + float(m_w.group(1))) * 1024.0, "source": os.path.basename(f),
-                    "note": "FETCH_SIZE + WRITE_SIZE, KiB -> bytes, uncorrected (4-byte gathers: uncalibrated on gfx950)"}
+            # FETCH_SIZE counts one 128-byte line fetch as 64 bytes on gfx950, for streamed and gathered reads alike
+            # (profiles/r03_fetch_size_calibration.txt, tools/fetch_calib.hip); WRITE_SIZE counts the bytes
+            best = {"bytes": (2.0 * float(m_f.group(1)) + float(m_w.group(1))) * 1024.0, "source": os.path.basename(f),
+                    "fetch_bytes": 2.0 * float(m_f.group(1)) * 1024.0, "write_bytes": float(m_w.group(1)) * 1024.0,
+                    "note": "2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950 tallies a 128-byte line fetch as 64 bytes; calibrated on this "
+                            "kernel's access shapes, profiles/r03_fetch_size_calibration.txt)"}
     return best
 
 

@@ -4,7 +4,8 @@
 
 Per kernel: average duration (kernel-trace stats) and the mean of every PMC counter per dispatch.
 SQ_* cycle counters are in quad-cycles. FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 prints them; FETCH_SIZE
-under-reports wide coalesced streaming reads by 2x on gfx950 (each 128-B request is tallied as 64 B).
+tallies every 128-byte line fetch as 64 bytes on gfx950, whatever the access shape (tools/fetch_calib.hip): bytes read
+= 2 x FETCH_SIZE x 1024.
 """
 import csv
 import glob
