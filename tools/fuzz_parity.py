@@ -24,6 +24,11 @@ from renderer_amd import scenes  # noqa: E402
 from renderer_amd.api import Renderer, default_settings, load_hip_capi  # noqa: E402
 
 
+# Diagnosis of pixels further apart than one step: FUZZ_SMOOTH=1 builds the same scenes with every sampler filter LINEAR,
+# 2 with MASK materials made OPAQUE, 3 both (the same random draws otherwise): what is left then is not a texel or
+# cut-off choice falling on either side.
+SMOOTH = int(os.environ.get("FUZZ_SMOOTH", "0"))
+DUMP = int(os.environ.get("FUZZ_DUMP", "0"))   # print up to this many of a frame's pixels that are further apart than one step
 BIG_FROM = 100000   # seeds from here on: larger frames, more primitives, more triangles, sometimes an RGBA16F output
 WIDE_FROM = 50000   # seeds from here on: also 1-4 cascades, up to 8 cubes, other gammas, all three exposure modes, orthographic cameras
 
@@ -81,8 +86,9 @@ def random_images(rng):
     return imgs
 
 
-def build(r, seed):
-    """Returns the meshes that may move: [(mesh id, model matrix, number of joints or 0)]."""
+def build(r, seed, only=None):
+    """Returns the meshes that may move: [(mesh id, model matrix, number of joints or 0)]. `only`: a set of primitive
+    numbers to keep (diagnosis: the same random draws, the other primitives left out)."""
     rng = np.random.default_rng(seed)
     big = seed >= BIG_FROM
     n_prims = int(rng.integers(8, 40)) if big else int(rng.integers(1, 6))
@@ -93,18 +99,29 @@ def build(r, seed):
         wrap = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
         filt = [int(rng.integers(0, 2)) if rng.random() < 0.3 else B.FILTER_LINEAR for _ in range(3)]
         mips = 1 if rng.random() < 0.2 else 0xFFFFFFFF
+        if SMOOTH & 1:
+            filt = [B.FILTER_LINEAR] * 3
         tex = [r.make_texture(r.load_image(a, f, mips), wrap[0], wrap[1], *filt) for a, f in imgs]
         if rng.random() < 0.2:
             tex[3] = tex[2]    # occlusion and metal-roughness in one image
         if rng.random() < 0.2:
             tex[int(rng.integers(0, 5))] = B.INVALID_ID   # a slot left to the renderer's default
         mode = int(rng.choice([B.ALPHA_OPAQUE, B.ALPHA_OPAQUE, B.ALPHA_MASK, B.ALPHA_BLEND]))
+        if (SMOOTH & 2) and mode == B.ALPHA_MASK:
+            mode = B.ALPHA_OPAQUE
         mat = scenes.make_material(tex, base_color=tuple(rng.uniform(0.2, 1.0, 4)), emissive=tuple(rng.uniform(0, 0.5, 3) * (rng.random() < 0.5)),
                                    metallic=float(rng.random()), roughness=float(rng.random()), ao=float(rng.uniform(0.5, 1.0)),
                                    alpha_mode=mode, alpha_cutoff=float(rng.uniform(0.2, 0.8)))
         model = scenes.translation(*rng.normal(0, 1.0, 3)) @ scenes.rotation_y(float(rng.uniform(0, 6.28))) @ scenes.rotation_x(float(rng.uniform(0, 6.28)))
         is_static = bool(rng.random() < 0.6)
-        if rng.random() < 0.25:
+        skinned = rng.random() < 0.25
+        if only is not None and p not in only:
+            if skinned:   # the draws a skinned primitive would have made
+                n_joints = int(rng.integers(2, 7)); nv = geo.pos.shape[0]
+                rng.integers(0, n_joints, (nv, 4)); rng.random((nv, 4)); rng.random((nv, 4)); rng.random()
+                rng.choice([B.UINT8, B.UINT16]); rng.choice([B.FLOAT, B.UINT8, B.UINT16]); joint_palette(rng, n_joints)
+            continue
+        if skinned:
             # a skinned primitive: 2-6 joints, four influences per vertex (some with zero weight, weights not normalised
             # in a tenth of the cases), joint indices and weights in a random storage type
             n_joints = int(rng.integers(2, 7))
@@ -166,7 +183,8 @@ def change(r, movable, seed, frame):
         r.fuzz_casters = sum(1 for l in lights if l[2])
 
 
-def one(seed, orc_capi, hip_capi, frames=2):
+def draw_settings(seed):
+    """Frame size, sample count, settings and frame parameters of a seed."""
     rng = np.random.default_rng(seed + 10 ** 6)
     W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
     if seed >= BIG_FROM:
@@ -181,6 +199,11 @@ def one(seed, orc_capi, hip_capi, frames=2):
     if seed >= WIDE_FROM:
         frame_kw = [dict(exposure_mode=0, delta_time=float(rng.uniform(0.001, 0.5))), dict(exposure_mode=1, temporal_luminance=float(rng.uniform(0.01, 4.0))),
                     dict(exposure_mode=2, exposure=float(rng.uniform(-3, 3)))][int(rng.integers(0, 3))]
+    return W, H, msaa, st, frame_kw
+
+
+def one(seed, orc_capi, hip_capi, frames=2):
+    W, H, msaa, st, frame_kw = draw_settings(seed)
     ro = Renderer(orc_capi, W, H, default_settings(**st), keep_intermediates=True)
     rh = Renderer(hip_capi, W, H, default_settings(**st), keep_intermediates=True)
     mo, mh = build(ro, seed), build(rh, seed)
@@ -221,6 +244,13 @@ def one(seed, orc_capi, hip_capi, frames=2):
             print(f"  seed {seed} frame {frame}: {int((diff > 1).sum())} of {diff.size} pixels apart, largest step {int(diff.max())}; avg log luminance {la} / {lb}; "
                   f"exposure {ro.frame_stats().exposure} / {rh.frame_stats().exposure}; {W}x{H} msaa {msaa} {st}")
         worst = max(worst, float((diff > 1).mean()))
+        if DUMP and (diff > 1).any():   # the pixels themselves: both outputs, both linear colours, who covers them
+            ho, hh = ro.read_hdr().astype(np.float64), rh.read_hdr().astype(np.float64)
+            vis = ro.read_visibility()
+            ys, xs = np.nonzero(diff > 1)
+            print(f"  seed {seed} frame {frame}: {ys.size} pixels apart ({W}x{H} msaa {msaa} {st} {frame_kw})")
+            for y, x in list(zip(ys, xs))[:DUMP]:
+                print(f"    ({x},{y}) out {a[y, x].tolist()} / {b[y, x].tolist()}  linear {np.round(ho[y, x, :3], 4).tolist()} / {np.round(hh[y, x, :3], 4).tolist()}  triangles {vis[:, y, x].tolist()}")
     ro.close(); rh.close()
     return True, worst
 
