@@ -221,7 +221,21 @@ def check_jittered(capi, seed, monkeypatch):
     cam["fov"] = float(np.float32(np.radians(rng.uniform(32.0, 52.0))))
     lights = [(tuple(np.asarray(p) + rng.uniform(-0.7, 0.7, 3)), tuple(np.asarray(i) * rng.uniform(0.5, 1.5, 3)), cast) for p, i, cast in K.DETAIL_LIGHTS]
     plain = [(tuple(np.asarray(p) + rng.uniform(-0.7, 0.7, 3)), tuple(np.asarray(i) * rng.uniform(0.5, 1.5, 3))) for p, i in K.POINT_LIGHTS]
-    if seed >= 1000:
+    if 2000 <= seed < 3000:
+        # lights a few centimetres above the ground (1 / d^2 of a very small d^2, light vectors that turn by a radian over a
+        # few pixels); the two that cast shadows stay half a metre up (nothing may come nearer to them than the 0.1 of
+        # their cube's near plane)
+        above = lambda h0, h1: (lambda x: (x, 0.1003 * x + float(rng.uniform(h0, h1)), float(rng.uniform(-7.0, 1.5))))(float(rng.uniform(-3.5, 3.5)))  # noqa: E731
+        lights = [(above(0.5, 1.0) if cast else above(0.03, 0.3), tuple(np.asarray(i) * (rng.uniform(0.05, 0.2) if cast else rng.uniform(0.002, 0.02))), cast)
+                  for p, i, cast in K.DETAIL_LIGHTS]
+        plain = [(above(0.03, 0.3), tuple(np.asarray(i) * rng.uniform(0.002, 0.02))) for p, i in K.POINT_LIGHTS]
+    if 3000 <= seed < 4000:
+        # the eye a hand above the ground, looking along it: N.V near 0 on everything horizontal (the 1e-3 floors of the
+        # geometry term, the edge of the BRDF table, Fresnel near 1), the far ground on the last levels of its mip chains
+        x = float(rng.uniform(-2.5, 2.5))
+        cam["position"] = (x, 0.1003 * x + float(rng.uniform(0.12, 0.3)), float(rng.uniform(3.9, 4.5)))   # in front of the ground's near edge (z = 3)
+        cam["euler"] = (float(rng.uniform(-0.03, 0.02)), float(rng.uniform(-0.04, 0.04)), 0.0)   # (the ground's corners stay in front of the eye)
+    if 1000 <= seed < 2000:
         # against the light: the camera low over the ground, the lights low on the far side of the scene, so that the ground
         # between them is seen at grazing angles with V.L near -1 (forward highlights, where N.H is formed from nearly
         # opposite vectors)
@@ -253,7 +267,7 @@ def check_jittered(capi, seed, monkeypatch):
     n_frag = int((valid & (det["prim"] >= 0)).sum())
     assert n_frag >= (800 if seed >= 1000 else 1200), f"only {n_frag} shaded fragments are pinned"
     # (against the light with glossy materials the float32 evaluation of a narrow lobe is itself worth 2e-3 on single pixels)
-    _assert_close(got, want, valid, rtol=2.5e-3 if seed >= 1000 else 1.5e-3, atol=2e-4, what=f"pbr.frag, {variant} scene, seed {seed}, msaa {msaa}, {W}x{H}")
+    _assert_close(got, want, valid, rtol=2.5e-3 if 1000 <= seed < 2000 else 1.5e-3, atol=2e-4, what=f"pbr.frag, {variant} scene, seed {seed}, msaa {msaa}, {W}x{H}")
     r.close()
     return n_frag
 
@@ -273,6 +287,19 @@ def test_grazing_highlights_against_the_light(orc_capi, seed, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(1000, 1012)))
 def test_grazing_highlights_against_the_light_hip(hip_capi, seed, monkeypatch):
+    print(check_jittered(hip_capi, seed, monkeypatch))
+
+
+@pytest.mark.parametrize("seed", [2000, 3001])
+def test_lights_close_to_the_ground_and_grazing_views(orc_capi, seed, monkeypatch):
+    """Seeds from 2000: point lights a few centimetres above the ground. Seeds from 3000: the eye a hand above the ground,
+    looking along it (N.V near 0, the last mip levels)."""
+    print(check_jittered(orc_capi, seed, monkeypatch))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(2000, 2008)) + list(range(3000, 3008)))
+def test_lights_close_to_the_ground_and_grazing_views_hip(hip_capi, seed, monkeypatch):
     print(check_jittered(hip_capi, seed, monkeypatch))
 
 
