@@ -9,6 +9,7 @@ CUBICSPLINE branch returns the nearest key. Skins do not exist in the reference 
 Conventions: matrices are numpy math-convention 4x4 float64 (M @ column vector; transpose before handing them to the
 C ABI, which is column-major); quaternions are (x, y, z, w) as in glTF."""
 import bisect
+import math
 
 import numpy as np
 
@@ -47,10 +48,34 @@ def quat_from_axis_angle(axis, angle):
 
 
 def trs_matrix(translation, rotation, scale):
-    m = np.eye(4)
-    m[:3, :3] = quat_to_matrix(rotation) * np.asarray(scale, np.float64)[None, :]
-    m[:3, 3] = translation
-    return m
+    """T * R * S as one 4x4: column j of the rotation scaled by scale[j] (the products quat_to_matrix forms, on plain
+    floats: a frame of an animated scene builds one of these per node)."""
+    x, y, z, w = np.asarray(rotation, np.float64).tolist()
+    sx, sy, sz = np.asarray(scale, np.float64).tolist()
+    tx, ty, tz = np.asarray(translation, np.float64).tolist()
+    return np.array([[(1 - 2 * (y * y + z * z)) * sx, (2 * (x * y - z * w)) * sy, (2 * (x * z + y * w)) * sz, tx],
+                     [(2 * (x * y + z * w)) * sx, (1 - 2 * (x * x + z * z)) * sy, (2 * (y * z - x * w)) * sz, ty],
+                     [(2 * (x * z - y * w)) * sx, (2 * (y * z + x * w)) * sy, (1 - 2 * (x * x + y * y)) * sz, tz],
+                     [0.0, 0.0, 0.0, 1.0]], np.float64)
+
+
+# The same interpolation on lists of floats, for Animation.value_at (called once per animated channel and frame: on
+# arrays of three or four elements numpy's call overhead is ten times the arithmetic).
+def _normalize_list(q):
+    x, y, z, w = q
+    n = math.sqrt(x * x + y * y + z * z + w * w)
+    return [x / n, y / n, z / n, w / n]
+
+
+def _slerp_list(a, b, u):
+    d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]
+    if d < 0.0:
+        b, d = [-v for v in b], -d
+    if d > 0.9995:
+        return _normalize_list([x + (y - x) * u for x, y in zip(a, b)])
+    th = math.acos(min(d, 1.0))
+    s0, s1, st = math.sin((1.0 - u) * th), math.sin(u * th), math.sin(th)
+    return [(s0 * x + s1 * y) / st for x, y in zip(a, b)]
 
 
 class Animation:
@@ -68,9 +93,10 @@ class Animation:
         want = 3 * n if interpolation == CUBICSPLINE else n
         if self.values.shape[0] != want:
             raise ValueError(f"{interpolation}: expected {want} value rows for {n} keys, got {self.values.shape[0]}")
+        self._rows = self.values.reshape(want, -1).tolist()   # the keys as lists of floats, for value_at
 
     def _key(self, i):
-        return self.values[3 * i + 1] if self.interpolation == CUBICSPLINE else self.values[i]
+        return self._rows[3 * i + 1] if self.interpolation == CUBICSPLINE else self._rows[i]
 
     def _wrap(self, t):
         t0, t1 = self.times[0], self.times[-1]
@@ -78,20 +104,24 @@ class Animation:
         if self.repeat == CLAMP or span <= 0.0:
             return min(max(t, t0), t1)
         u = (t - t0) / span
-        loops = np.floor(u)
+        loops = math.floor(u)
         frac = u - loops
-        if self.repeat == MIRROR and int(loops) % 2:
+        if self.repeat == MIRROR and loops % 2:
             frac = 1.0 - frac
         return t0 + frac * span
 
     def value_at(self, t):
+        return np.array(self._value_at(t), np.float64)
+
+    def _value_at(self, t):
+        """value_at as a list of floats."""
         if len(self.times) == 1:
-            return self._key(0).copy()
+            return list(self._key(0))
         t = self._wrap(float(t))
         i1 = bisect.bisect_right(self.times, t)
         if i1 >= len(self.times):
-            out = self._key(len(self.times) - 1).copy()
-            return quat_normalize(out) if self.rotation else out
+            out = list(self._key(len(self.times) - 1))
+            return _normalize_list(out) if self.rotation else out
         i0 = max(i1 - 1, 0)
         if i1 == 0:
             i1 = 1
@@ -99,15 +129,17 @@ class Animation:
         dt = t1 - t0
         u = min(max((t - t0) / dt, 0.0), 1.0)
         if self.interpolation == STEP:
-            out = self._key(i0).copy()
+            out = list(self._key(i0))
         elif self.interpolation == LINEAR:
-            out = quat_slerp(self._key(i0), self._key(i1), u) if self.rotation else self._key(i0) + (self._key(i1) - self._key(i0)) * u
+            k0, k1 = self._key(i0), self._key(i1)
+            out = _slerp_list(k0, k1, u) if self.rotation else [a + (b - a) * u for a, b in zip(k0, k1)]
         else:  # cubic Hermite, tangents scaled by the key spacing
-            v0, b0 = self.values[3 * i0 + 1], self.values[3 * i0 + 2]
-            a1, v1 = self.values[3 * i1], self.values[3 * i1 + 1]
+            v0, b0 = self._rows[3 * i0 + 1], self._rows[3 * i0 + 2]
+            a1, v1 = self._rows[3 * i1], self._rows[3 * i1 + 1]
             u2, u3 = u * u, u * u * u
-            out = (2 * u3 - 3 * u2 + 1) * v0 + dt * (u3 - 2 * u2 + u) * b0 + (-2 * u3 + 3 * u2) * v1 + dt * (u3 - u2) * a1
-        return quat_normalize(out) if self.rotation else out
+            c0, c1, c2, c3 = 2 * u3 - 3 * u2 + 1, dt * (u3 - 2 * u2 + u), -2 * u3 + 3 * u2, dt * (u3 - u2)
+            out = [c0 * p + c1 * q + c2 * r + c3 * s for p, q, r, s in zip(v0, b0, v1, a1)]
+        return _normalize_list(out) if self.rotation else out
 
 
 class Node:
@@ -144,7 +176,8 @@ class Node:
             c.set_animation_time(t)
 
     def recalculate_model(self, parent_model=None):  # Node.cpp:9-19
-        self.model = (np.eye(4) if parent_model is None else parent_model) @ self.local_matrix()
+        local = self.local_matrix()
+        self.model = local.copy() if parent_model is None else parent_model @ local
         for c in self.children:
             c.recalculate_model(self.model)
 
@@ -163,7 +196,14 @@ class Skin:
                              else np.asarray(inverse_bind_matrices, np.float64).reshape(n, 4, 4))
 
     def joint_matrices(self, mesh_model=None):
-        inv = np.eye(4) if mesh_model is None else np.linalg.inv(np.asarray(mesh_model, np.float64))
+        if mesh_model is None:
+            inv = np.eye(4)
+        else:
+            m = np.asarray(mesh_model, np.float64)
+            key = m.tobytes()
+            if getattr(self, "_inv_key", None) != key:   # the same mesh matrix frame after frame: inverted once
+                self._inv_key, self._inv = key, np.linalg.inv(m)
+            inv = self._inv
         return np.stack([inv @ j.model @ ib for j, ib in zip(self.joints, self.inverse_bind)])
 
     def palette_for_abi(self, mesh_model=None):
