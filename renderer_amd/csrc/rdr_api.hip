@@ -1879,6 +1879,9 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t W = c->W, H = c->H, S = c->settings.msaa;
     const size_t n = (size_t)W * H;
+    // The previous frame's vertex stage (k_shade_setup on stream3) reads the vertex arena and the pair counts, which
+    // exist once: nothing of this frame (geometry uploaded again, skinned vertices, set-up) may overtake it.
+    if (c->frames > 0) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vertex_out, 0));
     RDR_TRY(upload_scene(c));
     RDR_TRY(run_skinning(c));
     RDR_TRY(ensure_post_targets(c));
@@ -1921,8 +1924,6 @@ static int render_frame_impl(rdr_ctx* c, const rdr_frame_params* fp, uint8_t* ou
         const char* e = getenv("RDR_DEVICE_DRAW_LISTS");
         c->device_draws = e ? atoi(e) != 0 : c->prims.size() >= 2048;
     }
-    // the pair counts exist once: the previous frame's vertex stage (stream3) reads them until it is done
-    if (c->frames > 1) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_vertex_out, 0));
     HIP_TRY(hipMemsetAsync(frame_counters(c), 0, RDR_COUNTER_SLOT_BYTES, c->stream));
     if (c->device_draws) RDR_TRY(upload_cull_tables(c));  // the candidate lists the views below refer to
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
