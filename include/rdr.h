@@ -283,7 +283,10 @@ int rdr_set_lights(rdr_ctx* ctx, const rdr_point_light* lights, uint32_t count,
                    const rdr_directional_light* directional);
 /* VulkanRenderer::setEnvironmentMap (VulkanRendererEnvironment.cpp:71-125):
  * six RGBA32F faces in the order +X,-X,+Y,-Y,+Z,-Z (main.cpp:434-441); runs the
- * irradiance and GGX-prefilter bakes (…Environment.cpp:193-250, 324-391). */
+ * irradiance and GGX-prefilter bakes (…Environment.cpp:193-250, 324-391).
+ * The cubes and the BRDF table exist once per context: this call, rdr_set_environment_equirect, rdr_set_brdf_lut and
+ * rdr_generate_brdf_lut first wait for the frames in flight (which read them) to finish on the GPU; the finished
+ * frames' results are picked up as usual afterwards. */
 int rdr_set_environment_map(rdr_ctx* ctx, const float* const faces_rgba32f[6], uint32_t width, uint32_t height);
 /* The reference loads textures/ibl_brdf_lut.png in its constructor
  * (VulkanRenderer.cpp:44-45); here the caller hands over the decoded RGB(A)8

@@ -1665,6 +1665,16 @@ struct StreamTimer {
 };
 
 // Both bakes from the packed cube in d_env (the second half of setEnvironmentMap).
+// The environment cubes and the BRDF table exist once and every frame's shading reads them: a call that replaces them
+// first lets the frames in flight finish (their results stay where they are until they are picked up as usual).
+static int finish_frames_in_flight(rdr_ctx* c) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream3));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
+    HIP_TRY(hipStreamSynchronize(c->stream4));
+    return RDR_OK;
+}
+
 static int bake_environment(rdr_ctx* c, uint32_t w) {
     memset(&c->env, 0, sizeof c->env);
     c->env.texels = c->d_env.as<uint32_t>(); c->env.res = w; c->env.levels = 1;
@@ -1760,6 +1770,7 @@ int rdr_set_environment_map(rdr_ctx* c, const float* const faces[6], uint32_t w,
     if (!c || !faces || w == 0 || w != h) return fail(c, RDR_ERR_INVALID, "set_environment_map: faces must be square");
     for (int f = 0; f < 6; f++) if (!faces[f]) return fail(c, RDR_ERR_INVALID, "set_environment_map: null face");
     HIP_TRY(hipSetDevice(c->device));
+    RDR_TRY(finish_frames_in_flight(c));
     const size_t face_px = (size_t)w * w;
     HIP_TRY(c->d_env.ensure(6 * face_px * 4));
     DevBuf staging;
@@ -1777,6 +1788,7 @@ int rdr_set_environment_equirect(rdr_ctx* c, const float* pano, uint32_t w, uint
     if (!c || !pano || w == 0 || h == 0 || w > 32768 || h > 32768 || face_res == 0 || face_res > 8192)
         return fail(c, RDR_ERR_INVALID, "set_environment_equirect: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    RDR_TRY(finish_frames_in_flight(c));
     HIP_TRY(c->d_env.ensure((size_t)6 * face_res * face_res * 4));
     DevBuf staging;
     HIP_TRY(staging.ensure((size_t)w * h * 16));
@@ -1803,6 +1815,7 @@ static int make_lut_quads(rdr_ctx* c) {
 int rdr_generate_brdf_lut(rdr_ctx* c, uint32_t size, uint32_t samples) {
     if (!c || size == 0 || size > 4096 || samples == 0 || samples > 65536) return fail(c, RDR_ERR_INVALID, "generate_brdf_lut: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    RDR_TRY(finish_frames_in_flight(c));
     std::vector<float> trig(2 * (size_t)samples);
     for (uint32_t s = 0; s < samples; s++) {
         const float phi = 2.0f * 3.14159265359f * ((float)s / (float)samples);
@@ -1845,6 +1858,7 @@ int rdr_read_brdf_lut(rdr_ctx* c, uint8_t* out, uint32_t* ow, uint32_t* oh) {
 int rdr_set_brdf_lut(rdr_ctx* c, const uint8_t* px, uint32_t w, uint32_t h, uint32_t channels) {
     if (!c || !px || w == 0 || h == 0 || (channels != 3 && channels != 4)) return fail(c, RDR_ERR_INVALID, "set_brdf_lut: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    RDR_TRY(finish_frames_in_flight(c));
     std::vector<uint8_t> rgba((size_t)w * h * 4);
     for (size_t i = 0; i < (size_t)w * h; i++) {
         for (int k = 0; k < 3; k++) rgba[i * 4 + k] = px[i * channels + k];

@@ -192,7 +192,8 @@ def test_two_frames_in_flight_match_frame_by_frame_rendering(hip_capi, exposure_
 @pytest.mark.gpu
 @pytest.mark.parametrize("in_flight", [2, 3])
 def test_frames_in_flight_with_changing_scene_state(hip_capi, in_flight, monkeypatch):
-    """Between frames that are still in flight (two, or three with RDR_FRAMES_IN_FLIGHT=3) the caller moves the camera, a dynamic mesh and the lights, and now and
+    """Between frames that are still in flight (two, or three with RDR_FRAMES_IN_FLIGHT=3) the caller moves the camera, a dynamic mesh and the lights, replaces
+    the environment (frame 4) and the BRDF table (frame 6), adds a mesh with an image of its own (frame 5), and now and
     then asks for a frame in host memory (which drains the pipeline). Every frame must equal the same frame rendered by
     a second context one frame at a time: nothing a frame reads may be overwritten by the frame enqueued behind it."""
     import torch
@@ -214,6 +215,14 @@ def test_frames_in_flight_with_changing_scene_state(hip_capi, in_flight, monkeyp
         r.set_mesh_transform(ids["sphere"], m.T)
         r.set_lights([((1.5 - 0.2 * k, 2.2, 1.0 + 0.1 * k), (20.0 + 3 * k, 18.0, 14.0), True),
                       ((-1.0, 1.5 + 0.1 * k, 2.0), (6.0, 9.0 + k, 12.0), k % 2 == 0)], scenes.default_directional_light())
+        if k == 4:
+            r.set_environment_map(scenes.sky_faces(16, seed=9, sun_dir=(-0.5, 0.6, 0.2)))
+        if k == 5:
+            tex = scenes.material_textures(r, 32, 23)
+            r.add_mesh([scenes.upload_primitive(r, scenes.box(0.5, 0.5, 0.5, 1), scenes.make_material(tex), scenes.B.UINT16)],
+                       model=scenes.translation(-0.9, 0.6, 0.8).T, is_static=False)
+        if k == 6:
+            r.set_brdf_lut(scenes.brdf_lut(24, 24))
 
     params = dict(exposure_mode=1, temporal_luminance=0.4)
     r1, ids1 = build()
