@@ -10,21 +10,21 @@ from oracle import orc  # noqa: E402
 from renderer_amd.api import Renderer, default_settings, load_hip_capi  # noqa: E402
 
 seed = int(sys.argv[1])
-rng = np.random.default_rng(seed + 10 ** 6)
-W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
-msaa = int(rng.choice([1, 4]))
-st = dict(msaa=msaa, directional_shadow_map_resolution=int(rng.choice([64, 200, 512])), point_shadow_map_resolution=int(rng.choice([16, 50, 128])),
-          point_shadow_map_count=int(rng.integers(0, 4)), dynamic_shadows_enabled=int(rng.random() < 0.8))
-print(seed, W, H, st)
+W, H, msaa, st, frame_kw = F.draw_settings(seed)
+print(seed, W, H, st, frame_kw)
 ro = Renderer(orc.capi(), W, H, default_settings(**st), keep_intermediates=True)
 rh = Renderer(load_hip_capi(), W, H, default_settings(**st), keep_intermediates=True)
 F.build(ro, seed); F.build(rh, seed)
-a, la = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
-b, lb = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+a, la = ro.render_frame(**frame_kw)
+b, lb = rh.render_frame(**frame_kw)
 ho, hh = ro.read_hdr().astype(np.float64), rh.read_hdr().astype(np.float64)
 print("avg log luminance", la, lb)
 print("hdr non-finite: checker", int((~np.isfinite(ho)).sum()), "hip", int((~np.isfinite(hh)).sum()))
 fin = np.isfinite(ho) & np.isfinite(hh)
+for name, img, other in (("checker", ho, hh), ("hip", hh, ho)):
+    yn, xn = np.nonzero(~np.isfinite(img).all(-1))
+    for y, x in list(zip(yn, xn))[:4]:
+        print(f"  {name} non-finite at ({x},{y}): {img[y, x]}, the other side has {other[y, x]}, triangles {ro.read_visibility()[:, y, x].tolist()}")
 rel = np.abs(ho - hh) / (np.abs(ho) + 1e-3)
 bad = (rel > 5e-3) & fin
 print("hdr finite values apart by more than 0.5 %:", int(bad.sum()), "of", int(fin.sum()))
@@ -39,8 +39,8 @@ for level in range(6):
           "non-finite", int((~np.isfinite(bo)).sum()), int((~np.isfinite(bh)).sum()))
 d = np.abs(a.astype(int) - b.astype(int)).max(-1)
 print("8-bit frame: pixels apart by more than one step:", int((d > 1).sum()), "of", d.size)
-a1, la1 = ro.render_frame(exposure_mode=1, temporal_luminance=0.5)
-b1, lb1 = rh.render_frame(exposure_mode=1, temporal_luminance=0.5)
+a1, la1 = ro.render_frame(**frame_kw)
+b1, lb1 = rh.render_frame(**frame_kw)
 print("second frame (nothing moved): checker equals its first:", np.array_equal(a, a1), "hip equals its first:", np.array_equal(b, b1), "luminance", la1, lb1)
 ho1, hh1 = ro.read_hdr().astype(np.float64), rh.read_hdr().astype(np.float64)
 print("  hdr: checker equals its first:", np.array_equal(ho, ho1, equal_nan=True), "hip equals its first:", np.array_equal(hh, hh1, equal_nan=True))
