@@ -72,7 +72,8 @@ def measured_traffic(kernel):
     import re
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.txt"))):
-        block = re.search(r"^" + re.escape(kernel) + r":.*?(?=^\S)", open(f).read() + "\nend", re.S | re.M)
+        # (a templated kernel is listed with its arguments: "k_shade_frags<false>:")
+        block = re.search(r"^" + re.escape(kernel) + r"(?:<[^>\n]*>)?:.*?(?=^\S)", open(f).read() + "\nend", re.S | re.M)
         if not block:
             continue
         m_f = re.search(r"FETCH_SIZE\s+n=\d+\s+mean=([0-9.e+]+)", block.group(0))
