@@ -239,6 +239,8 @@ static void shade_fragment(const ShadeCtx& sc, const Draw& d, uint32_t tri, int 
     if (dbg_env) std::sscanf(dbg_env, "%d,%d", &dbg_x, &dbg_y);
     const bool dbg = px == dbg_x && py == dbg_y;
     if (dbg) std::fprintf(stderr, "[orc] px %d %d tri %u P %.9g %.9g %.9g N %.9g %.9g %.9g rough %.9g metal %.9g\n", px, py, tri, P.x, P.y, P.z, N.x, N.y, N.z, roughness, metallic);
+    if (dbg) for (int k = 0; k < 3; k++) std::fprintf(stderr, "[orc]   vertex %d: normal %.9g %.9g %.9g tangent %.9g %.9g %.9g bitangent %.9g %.9g %.9g -> %.9g %.9g %.9g lam %.9g\n", k, pr.attr[vi[k]].normal.x, pr.attr[vi[k]].normal.y, pr.attr[vi[k]].normal.z, pr.attr[vi[k]].tangent.x, pr.attr[vi[k]].tangent.y, pr.attr[vi[k]].tangent.z, pr.attr[vi[k]].bitangent.x, pr.attr[vi[k]].bitangent.y, pr.attr[vi[k]].bitangent.z, nrm[k].x, nrm[k].y, nrm[k].z, lam[0][k]);
+    if (dbg) std::fprintf(stderr, "[orc]   T %.9g %.9g %.9g B %.9g %.9g %.9g Nv %.9g %.9g %.9g normal texel %.9g %.9g %.9g\n", Tv.x, Tv.y, Tv.z, Bv.x, Bv.y, Bv.z, Nv.x, Nv.y, Nv.z, nx, ny, nz);
     for (const PointLight& pl : c.lights) {
         if (dbg) std::fprintf(stderr, "[orc]   Lo %.9g %.9g %.9g (before light at %.3g %.3g %.3g)\n", Lo.x, Lo.y, Lo.z, pl.point.x, pl.point.y, pl.point.z);
         const V3 Lv = pl.point - P;

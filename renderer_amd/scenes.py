@@ -249,7 +249,8 @@ def upload_skinned_primitive(r, geo, joints, weights, material, joint_type=B.UIN
         w = np.ascontiguousarray(weights, np.float32)
     else:
         top = 255 if weight_type == B.UINT8 else 65535
-        w = np.rint(np.asarray(weights, np.float64) * top).astype(np.uint8 if weight_type == B.UINT8 else np.uint16)
+        # (a normalised integer holds [0, 1]: a weight above 1 is stored as 1, not wrapped round to a small value)
+        w = np.rint(np.clip(np.asarray(weights, np.float64), 0.0, 1.0) * top).astype(np.uint8 if weight_type == B.UINT8 else np.uint16)
     parts = [geo.pos.tobytes(), geo.nrm.tobytes(), geo.tan.tobytes(), geo.uv.tobytes(), j.tobytes(), w.tobytes(), geo.idx.tobytes()]
     parts = [p + b"\0" * (-len(p) % 4) for p in parts]
     offs = np.cumsum([0] + [len(p) for p in parts])
